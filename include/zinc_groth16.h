@@ -1,0 +1,173 @@
+/* C ABI of libzinc_groth16_hip.so -- an MI355X (gfx950) Groth16 prover backend for zinc-vm.
+ *
+ * What it replaces.  zinc-vm proves through one generic Rust call,
+ *     franklin_crypto::bellman::groth16::create_random_proof(circuit, &params, rng)
+ * (zinc-vm/src/core/circuit/facade.rs:153, zinc-vm/src/core/contract/facade.rs:387), whose
+ * callee side is `Circuit::synthesize` (zinc-vm/src/core/circuit/synthesizer.rs:33-38).  The
+ * Rust side keeps a recording ConstraintSystem (the role bellman's ProvingAssignment plays)
+ * and hands what it recorded to the entry points below; everything after synthesis -- row
+ * evaluation, the seven FFTs, the eight multiexps, final assembly -- runs on the GPU.
+ *
+ * Conventions
+ *  - Field elements: 4 x u64 little-endian limbs, Montgomery form with R = 2^256 (the in-memory
+ *    layout of ff_ce's Fr/Fq, so a Rust &[Fr] is passed as-is).  32 bytes each.
+ *  - G1 affine point: x || y (64 bytes).  G2 affine point: x.c0 || x.c1 || y.c0 || y.c1
+ *    (128 bytes).  All-zero bytes encode the point at infinity.
+ *  - A variable index is a u32: bit 31 set = aux variable, clear = input variable; input 0 is
+ *    the constant ONE (zinc-vm/src/constraint_systems/main.rs:31).
+ *  - Every function returns a zg16_status; no exceptions or aborts cross this boundary.
+ *    Status values mirror the bellman SynthesisError variants that can occur after synthesis
+ *    (mapped by the caller at zinc-vm/src/core/circuit/facade.rs:154).
+ *  - Entry points block until the result is on the host.  A context is used by one thread at a
+ *    time.  The caller owns every host buffer; the library copies what it needs.
+ */
+#ifndef ZINC_GROTH16_H
+#define ZINC_GROTH16_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  ZG16_OK = 0,
+  ZG16_ERR_POLYNOMIAL_DEGREE_TOO_LARGE = 1, /* domain would need 2^28 or more rows            */
+  ZG16_ERR_UNEXPECTED_IDENTITY = 2,         /* identity base consumed, or delta at infinity   */
+  ZG16_ERR_ASSIGNMENT_MISSING = 3,          /* a witness vector is NULL or too short          */
+  ZG16_ERR_MALFORMED_KEY = 4,               /* key vector lengths do not fit the circuit      */
+  ZG16_ERR_INVALID_ARGUMENT = 5,
+  ZG16_ERR_DEVICE = 6,                      /* a HIP call failed; see zg16_last_error         */
+  ZG16_ERR_OUT_OF_MEMORY = 7
+} zg16_status;
+
+typedef struct zg16_ctx zg16_ctx;   /* one GPU, its streams and scratch memory */
+typedef struct zg16_pk zg16_pk;     /* a proving key resident in HBM           */
+typedef struct zg16_r1cs zg16_r1cs; /* recorded constraint matrices in HBM     */
+
+/* Host view of bellman's `Parameters<Bn256>` (what `Parameters::read` yields at
+ * zinc-vm/src/zvm/arguments/command/prove.rs:73-76).  a, b_g1, b_g2 hold points only for the
+ * variables whose polynomial is non-zero, inputs first (upstream drops identities at setup). */
+typedef struct {
+  const uint64_t* alpha_g1; /* 8  limbs */
+  const uint64_t* beta_g1;  /* 8  */
+  const uint64_t* beta_g2;  /* 16 */
+  const uint64_t* delta_g1; /* 8  */
+  const uint64_t* delta_g2; /* 16 */
+  const uint64_t* h;    size_t n_h;    /* G1, m - 1 points          */
+  const uint64_t* l;    size_t n_l;    /* G1, one per aux variable  */
+  const uint64_t* a;    size_t n_a;    /* G1                        */
+  const uint64_t* b_g1; size_t n_b_g1; /* G1                        */
+  const uint64_t* b_g2; size_t n_b_g2; /* G2                        */
+} zg16_pk_view;
+
+/* One constraint matrix in CSR form.  Rows are in enforce() order and must already include the
+ * `input_i * 0 = 0` rows bellman appends after synthesis (A has the single term input_i there).
+ * Within a row: no repeated variable and no zero coefficient -- the canonical form produced by
+ * zinc-vm/src/constraint_systems/dedup.rs:50-68. */
+typedef struct {
+  const uint64_t* row_ptr; /* n_rows + 1 offsets into col/coeff          */
+  const uint32_t* col;     /* variable index, bit 31 = aux               */
+  const uint64_t* coeff;   /* 4 limbs per entry, Montgomery Fr           */
+} zg16_csr;
+
+typedef struct {
+  size_t n_rows;
+  size_t n_inputs; /* including ONE */
+  size_t n_aux;
+  zg16_csr a, b, c;
+} zg16_r1cs_view;
+
+/* Groth16 proof as three affine points (bellman `Proof<Bn256>`, returned by value at
+ * zinc-vm/src/core/circuit/facade.rs:153). */
+typedef struct {
+  uint64_t a[8];  /* G1 */
+  uint64_t b[16]; /* G2 */
+  uint64_t c[8];  /* G1 */
+} zg16_proof;
+
+/* Partial result of one GPU's share of a proof: the multiexp sums over that GPU's point range,
+ * in extended Jacobian XYZZ coordinates (Montgomery limbs).  Partials from all shards are summed
+ * coordinate-free by zg16_prove_finish, so they can be gathered with any byte-moving collective. */
+typedef struct {
+  uint64_t hl[16];   /* G1: h-query + l-query   */
+  uint64_t a[16];    /* G1: a-query             */
+  uint64_t b1[16];   /* G1: b_g1-query          */
+  uint64_t b2[32];   /* G2: b_g2-query          */
+} zg16_partial;
+
+/* ---- context ------------------------------------------------------------------------------ */
+zg16_status zg16_ctx_create(int device_id, zg16_ctx** out);
+void        zg16_ctx_destroy(zg16_ctx* ctx);
+/* Text of the most recent failure on this context (never NULL). */
+const char* zg16_last_error(const zg16_ctx* ctx);
+/* Make the context issue its work on a caller-owned hipStream_t (NULL = its own stream). */
+zg16_status zg16_ctx_set_stream(zg16_ctx* ctx, void* hip_stream);
+
+/* ---- proving key -------------------------------------------------------------------------- */
+/* Upload the slice [shard_index/shard_count] of every query (contiguous point ranges) so that
+ * `shard_count` GPUs each hold 1/shard_count of the key.  shard_count = 1 uploads all of it. */
+zg16_status zg16_pk_upload(zg16_ctx* ctx, const zg16_pk_view* view, int shard_index,
+                           int shard_count, zg16_pk** out);
+void        zg16_pk_free(zg16_pk* pk);
+
+/* ---- constraint matrices ------------------------------------------------------------------ */
+/* Upload A, B, C once per circuit; the structure does not depend on the witness.  Computes the
+ * A/B density maps (which variables own a base in the a / b queries) on the device. */
+zg16_status zg16_r1cs_upload(zg16_ctx* ctx, const zg16_r1cs_view* view, zg16_r1cs** out);
+void        zg16_r1cs_free(zg16_r1cs* r1cs);
+/* popcounts of the density maps: a_aux, b_input, b_aux (any pointer may be NULL). */
+zg16_status zg16_r1cs_density(const zg16_r1cs* r1cs, size_t* a_aux, size_t* b_input, size_t* b_aux);
+
+/* ---- prove -------------------------------------------------------------------------------- */
+/* bellman `create_proof(circuit, params, r, s)`: z_in has n_inputs elements (z_in[0] = ONE),
+ * z_aux has n_aux elements, r and s are Montgomery Fr.  Witness pointers are host memory unless
+ * `witness_on_device` is non-zero, in which case they are device pointers on ctx's GPU. */
+zg16_status zg16_prove(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1cs* r1cs,
+                       const uint64_t* z_in, const uint64_t* z_aux, int witness_on_device,
+                       const uint64_t r[4], const uint64_t s[4], zg16_proof* out);
+
+/* Multi-GPU form: every rank calls zg16_prove_partial with its key shard (and the full
+ * witness); the partials are gathered (RCCL all_gather / host copy) and any one rank calls
+ * zg16_prove_finish on the full list.  The vk points come from the same zg16_pk_view. */
+zg16_status zg16_prove_partial(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1cs* r1cs,
+                               const uint64_t* z_in, const uint64_t* z_aux, int witness_on_device,
+                               zg16_partial* out);
+zg16_status zg16_prove_finish(const zg16_pk_view* vk_points, const zg16_partial* partials,
+                              size_t n_partials, const uint64_t r[4], const uint64_t s[4],
+                              zg16_proof* out);
+
+/* ---- stand-alone stages (each is one stage of bellman's prover) ------------------------------
+ * data: 2^log_n Montgomery Fr, natural order in and out, transformed in place.
+ * inverse = 0: `EvaluationDomain::fft`; inverse = 1: `ifft` (includes the 1/m factor);
+ * coset != 0 selects `coset_fft` / `icoset_fft` (multiplicative generator 7). */
+zg16_status zg16_ntt(zg16_ctx* ctx, uint64_t* data, unsigned log_n, int inverse, int coset,
+                     int on_device);
+/* H coefficients from row evaluations a, b, c (n_rows each): 3 ifft, 3 coset_fft, pointwise
+ * a*b-c, divide by Z on the coset, icoset_fft.  Writes m - 1 Montgomery Fr to h. */
+zg16_status zg16_h_coefficients(zg16_ctx* ctx, const uint64_t* a, const uint64_t* b,
+                                const uint64_t* c, size_t n_rows, uint64_t* h, size_t* m_out);
+/* bellman `multiexp`: sum_i scalars[i] * bases[i].  Scalars are Montgomery Fr.  If `density` is
+ * non-NULL it has one byte per scalar; bases then hold points only for the non-zero bytes, in
+ * order, and n_bases must equal their count.  Result is an affine point. */
+zg16_status zg16_msm_g1(zg16_ctx* ctx, const uint64_t* bases, size_t n_bases,
+                        const uint64_t* scalars, size_t n_scalars, const uint8_t* density,
+                        uint64_t out[8]);
+zg16_status zg16_msm_g2(zg16_ctx* ctx, const uint64_t* bases, size_t n_bases,
+                        const uint64_t* scalars, size_t n_scalars, const uint8_t* density,
+                        uint64_t out[16]);
+/* Row evaluations <A_row, z>, <B_row, z>, <C_row, z> (n_rows Montgomery Fr each, host memory). */
+zg16_status zg16_spmv(zg16_ctx* ctx, const zg16_r1cs* r1cs, const uint64_t* z_in,
+                      const uint64_t* z_aux, uint64_t* a, uint64_t* b, uint64_t* c);
+
+/* ---- timing of the last zg16_prove / zg16_prove_partial on this context -------------------- */
+typedef struct {
+  float upload_ms, spmv_ms, ntt_ms, msm_g1_ms, msm_g2_ms, finish_ms, total_ms;
+} zg16_timings;
+zg16_status zg16_last_timings(const zg16_ctx* ctx, zg16_timings* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZINC_GROTH16_H */

@@ -1,0 +1,497 @@
+// C ABI entry points (include/zinc_groth16.h) and the prove pipeline.
+//
+// The pipeline follows bellman_ce 0.3.0 `create_proof` stage for stage (the reference calls it at
+// zinc-vm/src/core/circuit/facade.rs:153 and zinc-vm/src/core/contract/facade.rs:387):
+//   row evaluation -> H coefficients -> multiexps -> assembly of A, B, C.
+// Two algebraic merges keep the launch count down without changing any result: the in/aux halves
+// of the a, b_g1 and b_g2 queries are summed in one multiexp each (only their sum enters A, B, C),
+// and the h and l queries share one multiexp (both only enter C).
+#include <string.h>
+
+#include <chrono>
+
+#include <memory>
+
+#include "r1cs.cuh"
+
+using namespace zg;
+
+namespace {
+
+constexpr uint32_t AUX_BIT = 0x80000000u;
+
+template <class T>
+zg16_status dev_alloc_copy(zg16_ctx* ctx, T** dst, const void* src, size_t count) {
+  *dst = nullptr;
+  if (!count) return ZG16_OK;
+  ZG_HIP(ctx, hipMalloc((void**)dst, count * sizeof(T)));
+  ZG_HIP(ctx, hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice));
+  return ZG16_OK;
+}
+
+void shard_range(size_t n, int idx, int cnt, size_t* lo, size_t* hi) {
+  *lo = n * (size_t)idx / (size_t)cnt;
+  *hi = n * (size_t)(idx + 1) / (size_t)cnt;
+}
+
+Fr load_fr(const uint64_t* p) {
+  Fr r;
+  memcpy(r.v, p, 32);
+  return r;
+}
+
+struct Timer {
+  zg16_ctx* ctx;
+  hipEvent_t a, b;
+  explicit Timer(zg16_ctx* c) : ctx(c), a(c->ev[0]), b(c->ev[1]) {}
+  void start() { (void)hipEventRecord(a, ctx->stream); }
+  float stop() {
+    (void)hipEventRecord(b, ctx->stream);
+    (void)hipEventSynchronize(b);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, a, b);
+    return ms;
+  }
+};
+
+// Device witness z = z_in || z_aux in scratch slot 3.
+zg16_status stage_witness(zg16_ctx* ctx, const zg16_r1cs* r, const uint64_t* z_in, const uint64_t* z_aux,
+                          int on_device, Fr** z_out) {
+  if (!z_in || (r->n_aux && !z_aux)) return fail(ctx, ZG16_ERR_ASSIGNMENT_MISSING, "witness pointer is NULL");
+  Fr* z;
+  ZG_TRY(scratch_get(ctx, 3, (r->n_in + r->n_aux) * sizeof(Fr), (void**)&z));
+  const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  ZG_HIP(ctx, hipMemcpyAsync(z, z_in, r->n_in * sizeof(Fr), kind, ctx->stream));
+  if (r->n_aux) ZG_HIP(ctx, hipMemcpyAsync(z + r->n_in, z_aux, r->n_aux * sizeof(Fr), kind, ctx->stream));
+  *z_out = z;
+  return ZG16_OK;
+}
+
+zg16_status check_key_fits(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1cs* r) {
+  const size_t m = (size_t)1 << r->log_m;
+  if (pk->n_h + 1 < m || pk->n_l != r->n_aux || pk->n_a != r->n_a || pk->n_b1 != r->n_b || pk->n_b2 != r->n_b)
+    return fail(ctx, ZG16_ERR_MALFORMED_KEY,
+                "key does not fit circuit: h %zu (need %zu), l %zu (aux %zu), a %zu (need %zu), b_g1 %zu b_g2 %zu (need %zu)",
+                pk->n_h, m - 1, pk->n_l, r->n_aux, pk->n_a, r->n_a, pk->n_b1, pk->n_b2, r->n_b);
+  return ZG16_OK;
+}
+
+template <class F, class RunFn>
+zg16_status msm_entry(zg16_ctx* ctx, const uint64_t* bases, size_t n_bases, const uint64_t* scalars,
+                             size_t n_scalars, const uint8_t* density, Affine<F>* out, RunFn run) {
+  if (!ctx || !out || (n_bases && !bases) || (n_scalars && !scalars)) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "bad arguments to multiexp");
+  ZG_HIP(ctx, hipSetDevice(ctx->device));
+  std::vector<uint32_t> map;
+  if (density) {
+    for (size_t i = 0; i < n_scalars; i++)
+      if (density[i]) map.push_back((uint32_t)i);
+    if (map.size() != n_bases) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "density selects %zu scalars for %zu bases", map.size(), n_bases);
+  } else if (n_bases != n_scalars) {
+    return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "%zu bases for %zu scalars", n_bases, n_scalars);
+  }
+  char* buf;
+  const size_t b_bytes = n_bases * sizeof(Affine<F>), s_bytes = n_scalars * sizeof(Fr), m_bytes = map.size() * 4;
+  ZG_TRY(scratch_get(ctx, 5, b_bytes + s_bytes + m_bytes + 768, (void**)&buf));
+  Affine<F>* d_b = (Affine<F>*)buf;
+  Fr* d_s = (Fr*)(buf + ((b_bytes + 255) & ~(size_t)255));
+  uint32_t* d_m = (uint32_t*)((char*)d_s + ((s_bytes + 255) & ~(size_t)255));
+  if (n_bases) ZG_HIP(ctx, hipMemcpyAsync(d_b, bases, b_bytes, hipMemcpyHostToDevice, ctx->stream));
+  if (n_scalars) ZG_HIP(ctx, hipMemcpyAsync(d_s, scalars, s_bytes, hipMemcpyHostToDevice, ctx->stream));
+  if (m_bytes) ZG_HIP(ctx, hipMemcpyAsync(d_m, map.data(), m_bytes, hipMemcpyHostToDevice, ctx->stream));
+  ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  MsmJob<F> job = {d_b, d_s, density ? d_m : nullptr, n_bases};
+  XYZZ<F> res;
+  ZG_TRY(run(ctx, &job, 1, &res));
+  *out = to_affine(res);
+  return ZG16_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+zg16_status zg16_ctx_create(int device_id, zg16_ctx** out) {
+  if (!out) return ZG16_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || device_id < 0 || device_id >= count) return ZG16_ERR_DEVICE;
+  if (hipSetDevice(device_id) != hipSuccess) return ZG16_ERR_DEVICE;
+  zg16_ctx* ctx = new zg16_ctx();
+  ctx->device = device_id;
+  if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) != hipSuccess) {
+    delete ctx;
+    return ZG16_ERR_DEVICE;
+  }
+  ctx->stream = ctx->own_stream;
+  for (auto& e : ctx->ev)
+    if (hipEventCreate(&e) != hipSuccess) {
+      delete ctx;
+      return ZG16_ERR_DEVICE;
+    }
+  *out = ctx;
+  return ZG16_OK;
+}
+
+void zg16_ctx_destroy(zg16_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipDeviceSynchronize();
+  ntt_free_domains(ctx);
+  for (auto& s : ctx->scratch)
+    if (s) (void)hipFree(s);
+  for (auto& e : ctx->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
+  delete ctx;
+}
+
+const char* zg16_last_error(const zg16_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
+
+zg16_status zg16_ctx_set_stream(zg16_ctx* ctx, void* hip_stream) {
+  if (!ctx) return ZG16_ERR_INVALID_ARGUMENT;
+  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  return ZG16_OK;
+}
+
+// ---------------------------------------------------------------------------------- proving key
+zg16_status zg16_pk_upload(zg16_ctx* ctx, const zg16_pk_view* v, int shard_index, int shard_count, zg16_pk** out) {
+  if (!ctx || !v || !out || shard_count < 1 || shard_index < 0 || shard_index >= shard_count)
+    return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "bad arguments to zg16_pk_upload");
+  *out = nullptr;
+  if (!v->alpha_g1 || !v->beta_g1 || !v->beta_g2 || !v->delta_g1 || !v->delta_g2)
+    return fail(ctx, ZG16_ERR_MALFORMED_KEY, "verifying-key points missing");
+  if (v->n_b_g1 != v->n_b_g2) return fail(ctx, ZG16_ERR_MALFORMED_KEY, "b_g1 and b_g2 lengths differ");
+  ZG_HIP(ctx, hipSetDevice(ctx->device));
+  std::unique_ptr<zg16_pk, void (*)(zg16_pk*)> pk(new zg16_pk(), zg16_pk_free);
+  pk->ctx = ctx;
+  pk->shard_index = shard_index;
+  pk->shard_count = shard_count;
+  pk->n_h = v->n_h; pk->n_l = v->n_l; pk->n_a = v->n_a; pk->n_b1 = v->n_b_g1; pk->n_b2 = v->n_b_g2;
+  shard_range(v->n_h, shard_index, shard_count, &pk->lo_h, &pk->hi_h);
+  shard_range(v->n_l, shard_index, shard_count, &pk->lo_l, &pk->hi_l);
+  shard_range(v->n_a, shard_index, shard_count, &pk->lo_a, &pk->hi_a);
+  shard_range(v->n_b_g1, shard_index, shard_count, &pk->lo_b, &pk->hi_b);
+  ZG_TRY(dev_alloc_copy(ctx, &pk->h, v->h + 8 * pk->lo_h, pk->hi_h - pk->lo_h));
+  ZG_TRY(dev_alloc_copy(ctx, &pk->l, v->l + 8 * pk->lo_l, pk->hi_l - pk->lo_l));
+  ZG_TRY(dev_alloc_copy(ctx, &pk->a, v->a + 8 * pk->lo_a, pk->hi_a - pk->lo_a));
+  ZG_TRY(dev_alloc_copy(ctx, &pk->b1, v->b_g1 + 8 * pk->lo_b, pk->hi_b - pk->lo_b));
+  ZG_TRY(dev_alloc_copy(ctx, &pk->b2, v->b_g2 + 16 * pk->lo_b, pk->hi_b - pk->lo_b));
+  memcpy(&pk->alpha_g1, v->alpha_g1, 64);
+  memcpy(&pk->beta_g1, v->beta_g1, 64);
+  memcpy(&pk->delta_g1, v->delta_g1, 64);
+  memcpy(&pk->beta_g2, v->beta_g2, 128);
+  memcpy(&pk->delta_g2, v->delta_g2, 128);
+  *out = pk.release();
+  return ZG16_OK;
+}
+
+void zg16_pk_free(zg16_pk* pk) {
+  if (!pk) return;
+  if (pk->ctx) (void)hipSetDevice(pk->ctx->device);
+  (void)hipFree(pk->h); (void)hipFree(pk->l); (void)hipFree(pk->a); (void)hipFree(pk->b1); (void)hipFree(pk->b2);
+  delete pk;
+}
+
+// --------------------------------------------------------------------------- constraint matrices
+zg16_status zg16_r1cs_upload(zg16_ctx* ctx, const zg16_r1cs_view* v, zg16_r1cs** out) {
+  if (!ctx || !v || !out) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "bad arguments to zg16_r1cs_upload");
+  *out = nullptr;
+  if (v->n_inputs < 1) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "n_inputs must include the constant ONE");
+  if (v->n_inputs + v->n_aux >= 0x7fffffffull || v->n_inputs >= AUX_BIT || v->n_aux >= AUX_BIT)
+    return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "too many variables");
+  const unsigned log_m = ceil_log2(v->n_rows ? v->n_rows : 1);
+  // bellman's EvaluationDomain::from_coeffs gives up once the exponent reaches Fr's two-adicity
+  if (log_m >= 28) return fail(ctx, ZG16_ERR_POLYNOMIAL_DEGREE_TOO_LARGE, "%zu rows need a domain of 2^%u", v->n_rows, log_m);
+  ZG_HIP(ctx, hipSetDevice(ctx->device));
+  std::unique_ptr<zg16_r1cs, void (*)(zg16_r1cs*)> r(new zg16_r1cs(), zg16_r1cs_free);
+  r->ctx = ctx;
+  r->n_rows = v->n_rows; r->n_in = v->n_inputs; r->n_aux = v->n_aux; r->log_m = log_m;
+  const zg16_csr* mats[3] = {&v->a, &v->b, &v->c};
+  std::vector<uint8_t> dens_a(v->n_aux, 0), dens_b_in(v->n_inputs, 0), dens_b_aux(v->n_aux, 0);
+  for (int k = 0; k < 3; k++) {
+    const zg16_csr& m = *mats[k];
+    if (!m.row_ptr) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "matrix %d has no row_ptr", k);
+    const size_t nnz = (size_t)m.row_ptr[v->n_rows];
+    if (nnz >= 0xffffffffull) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "matrix %d has too many entries", k);
+    if (nnz && (!m.col || !m.coeff)) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "matrix %d has no col/coeff", k);
+    std::vector<uint32_t> rp(v->n_rows + 1), flat(nnz), longs;
+    for (size_t i = 0; i <= v->n_rows; i++) {
+      if (m.row_ptr[i] > nnz || (i && m.row_ptr[i] < m.row_ptr[i - 1]))
+        return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "matrix %d row_ptr is not monotone", k);
+      rp[i] = (uint32_t)m.row_ptr[i];
+      if (i && rp[i] - rp[i - 1] > SPMV_LONG_ROW) longs.push_back((uint32_t)(i - 1));
+    }
+    for (size_t e = 0; e < nnz; e++) {
+      const uint32_t c = m.col[e];
+      if (c & AUX_BIT) {
+        const uint32_t i = c & ~AUX_BIT;
+        if (i >= v->n_aux) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "matrix %d names aux variable %u of %zu", k, i, v->n_aux);
+        flat[e] = (uint32_t)v->n_inputs + i;
+        if (k == 0) dens_a[i] = 1;
+        if (k == 1) dens_b_aux[i] = 1;
+      } else {
+        if (c >= v->n_inputs) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "matrix %d names input %u of %zu", k, c, v->n_inputs);
+        flat[e] = c;
+        if (k == 1) dens_b_in[c] = 1;
+      }
+    }
+    R1csMatrix& d = r->m[k];
+    d.nnz = nnz;
+    d.n_long = (uint32_t)longs.size();
+    ZG_TRY(dev_alloc_copy(ctx, &d.row_ptr, rp.data(), rp.size()));
+    ZG_TRY(dev_alloc_copy(ctx, &d.col, flat.data(), nnz));
+    ZG_TRY(dev_alloc_copy(ctx, &d.coeff, m.coeff, nnz));
+    ZG_TRY(dev_alloc_copy(ctx, &d.long_rows, longs.data(), longs.size()));
+  }
+  // query maps: A treats every input as dense (upstream tracks A density for aux only)
+  std::vector<uint32_t> a_map, b_map;
+  a_map.reserve(v->n_inputs + v->n_aux);
+  for (size_t i = 0; i < v->n_inputs; i++) a_map.push_back((uint32_t)i);
+  for (size_t i = 0; i < v->n_aux; i++)
+    if (dens_a[i]) { a_map.push_back((uint32_t)(v->n_inputs + i)); r->n_a_aux++; }
+  for (size_t i = 0; i < v->n_inputs; i++)
+    if (dens_b_in[i]) { b_map.push_back((uint32_t)i); r->n_b_in++; }
+  for (size_t i = 0; i < v->n_aux; i++)
+    if (dens_b_aux[i]) { b_map.push_back((uint32_t)(v->n_inputs + i)); r->n_b_aux++; }
+  r->n_a = a_map.size();
+  r->n_b = b_map.size();
+  ZG_TRY(dev_alloc_copy(ctx, &r->a_map, a_map.data(), a_map.size()));
+  ZG_TRY(dev_alloc_copy(ctx, &r->b_map, b_map.data(), b_map.size()));
+  *out = r.release();
+  return ZG16_OK;
+}
+
+void zg16_r1cs_free(zg16_r1cs* r) {
+  if (!r) return;
+  if (r->ctx) (void)hipSetDevice(r->ctx->device);
+  for (auto& m : r->m) {
+    (void)hipFree(m.row_ptr); (void)hipFree(m.col); (void)hipFree(m.coeff); (void)hipFree(m.long_rows);
+  }
+  (void)hipFree(r->a_map); (void)hipFree(r->b_map);
+  delete r;
+}
+
+zg16_status zg16_r1cs_density(const zg16_r1cs* r, size_t* a_aux, size_t* b_input, size_t* b_aux) {
+  if (!r) return ZG16_ERR_INVALID_ARGUMENT;
+  if (a_aux) *a_aux = r->n_a_aux;
+  if (b_input) *b_input = r->n_b_in;
+  if (b_aux) *b_aux = r->n_b_aux;
+  return ZG16_OK;
+}
+
+// ---------------------------------------------------------------------------------------- prove
+zg16_status zg16_prove_partial(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1cs* r, const uint64_t* z_in,
+                               const uint64_t* z_aux, int on_device, zg16_partial* out) {
+  if (!ctx || !pk || !r || !out) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "bad arguments to zg16_prove_partial");
+  if (pk->ctx != ctx || r->ctx != ctx) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "handles belong to another context");
+  ZG_TRY(check_key_fits(ctx, pk, r));
+  ZG_HIP(ctx, hipSetDevice(ctx->device));
+  zg16_timings& tm = ctx->timings;
+  tm = zg16_timings();
+  hipEvent_t e_begin = ctx->ev[2], e_end = ctx->ev[3];
+  ZG_HIP(ctx, hipEventRecord(e_begin, ctx->stream));
+  Timer t(ctx);
+  const size_t m = (size_t)1 << r->log_m;
+
+  t.start();
+  Fr* z;
+  ZG_TRY(stage_witness(ctx, r, z_in, z_aux, on_device, &z));
+  Fr* abc;
+  ZG_TRY(scratch_get(ctx, 4, 3 * m * sizeof(Fr), (void**)&abc));
+  Fr *a = abc, *b = abc + m, *c = abc + 2 * m;
+  if (m > r->n_rows)
+    for (Fr* p : {a, b, c}) ZG_HIP(ctx, hipMemsetAsync(p + r->n_rows, 0, (m - r->n_rows) * sizeof(Fr), ctx->stream));
+  tm.upload_ms = t.stop();
+
+  t.start();
+  ZG_TRY(spmv_device(ctx, r, z, a, b, c));
+  tm.spmv_ms = t.stop();
+
+  t.start();
+  ZG_TRY(h_pipeline_device(ctx, a, b, c, r->log_m));
+  tm.ntt_ms = t.stop();
+
+  t.start();
+  G1XYZZ hl, qa, qb1;
+  G2XYZZ qb2;
+  {
+    // h covers coefficients 0..m-2; this shard owns [lo_h, hi_h) clipped to that range
+    const size_t hi_h = pk->hi_h < m - 1 ? pk->hi_h : m - 1;
+    const size_t lo_h = pk->lo_h < hi_h ? pk->lo_h : hi_h;
+    MsmJob<Fq> jobs[2] = {{pk->h, a + lo_h, nullptr, hi_h - lo_h},
+                          {pk->l, z + r->n_in + pk->lo_l, nullptr, pk->hi_l - pk->lo_l}};
+    ZG_TRY(msm_g1_device(ctx, jobs, 2, &hl));
+    MsmJob<Fq> ja = {pk->a, z, r->a_map + pk->lo_a, pk->hi_a - pk->lo_a};
+    ZG_TRY(msm_g1_device(ctx, &ja, 1, &qa));
+    MsmJob<Fq> jb = {pk->b1, z, r->b_map + pk->lo_b, pk->hi_b - pk->lo_b};
+    ZG_TRY(msm_g1_device(ctx, &jb, 1, &qb1));
+  }
+  tm.msm_g1_ms = t.stop();
+  t.start();
+  {
+    MsmJob<Fq2> jb = {pk->b2, z, r->b_map + pk->lo_b, pk->hi_b - pk->lo_b};
+    ZG_TRY(msm_g2_device(ctx, &jb, 1, &qb2));
+  }
+  tm.msm_g2_ms = t.stop();
+  memcpy(out->hl, &hl, sizeof hl);
+  memcpy(out->a, &qa, sizeof qa);
+  memcpy(out->b1, &qb1, sizeof qb1);
+  memcpy(out->b2, &qb2, sizeof qb2);
+  ZG_HIP(ctx, hipEventRecord(e_end, ctx->stream));
+  ZG_HIP(ctx, hipEventSynchronize(e_end));
+  ZG_HIP(ctx, hipEventElapsedTime(&tm.total_ms, e_begin, e_end));
+  return ZG16_OK;
+}
+
+zg16_status zg16_prove_finish(const zg16_pk_view* v, const zg16_partial* parts, size_t n_parts, const uint64_t r_[4],
+                              const uint64_t s_[4], zg16_proof* out) {
+  if (!v || !parts || !n_parts || !r_ || !s_ || !out) return ZG16_ERR_INVALID_ARGUMENT;
+  if (!v->alpha_g1 || !v->beta_g1 || !v->beta_g2 || !v->delta_g1 || !v->delta_g2) return ZG16_ERR_MALFORMED_KEY;
+  G1Affine alpha1, beta1, delta1;
+  G2Affine beta2, delta2;
+  memcpy(&alpha1, v->alpha_g1, 64);
+  memcpy(&beta1, v->beta_g1, 64);
+  memcpy(&delta1, v->delta_g1, 64);
+  memcpy(&beta2, v->beta_g2, 128);
+  memcpy(&delta2, v->delta_g2, 128);
+  // bellman rejects a key whose delta is the identity before doing any work
+  if (delta1.is_inf() || delta2.is_inf()) return ZG16_ERR_UNEXPECTED_IDENTITY;
+  G1XYZZ hl = G1XYZZ::inf(), qa = G1XYZZ::inf(), qb1 = G1XYZZ::inf();
+  G2XYZZ qb2 = G2XYZZ::inf();
+  for (size_t i = 0; i < n_parts; i++) {
+    G1XYZZ p;
+    G2XYZZ p2;
+    memcpy(&p, parts[i].hl, sizeof p); add_full(hl, p);
+    memcpy(&p, parts[i].a, sizeof p); add_full(qa, p);
+    memcpy(&p, parts[i].b1, sizeof p); add_full(qb1, p);
+    memcpy(&p2, parts[i].b2, sizeof p2); add_full(qb2, p2);
+  }
+  const Fr rm = load_fr(r_), sm = load_fr(s_);
+  const Fr rc = from_mont(rm), sc = from_mont(sm), rsc = from_mont(mul(rm, sm));
+  const G1XYZZ d1 = G1XYZZ::from_affine(delta1), a1 = G1XYZZ::from_affine(alpha1), b1 = G1XYZZ::from_affine(beta1);
+  const G2XYZZ d2 = G2XYZZ::from_affine(delta2);
+  // A = alpha + r*delta + a_query
+  G1XYZZ A = scalar_mul(d1, rc.v);
+  add_mixed(A, alpha1);
+  add_full(A, qa);
+  // B = beta + s*delta + b_query   (G2)
+  G2XYZZ B = scalar_mul(d2, sc.v);
+  add_mixed(B, beta2);
+  add_full(B, qb2);
+  // C = rs*delta + s*alpha + r*beta + s*a_query + r*b_query(G1) + h + l
+  G1XYZZ C = scalar_mul(d1, rsc.v);
+  add_full(C, scalar_mul(a1, sc.v));
+  add_full(C, scalar_mul(b1, rc.v));
+  add_full(C, scalar_mul(qa, sc.v));
+  add_full(C, scalar_mul(qb1, rc.v));
+  add_full(C, hl);
+  const G1Affine Aa = to_affine(A), Ca = to_affine(C);
+  const G2Affine Ba = to_affine(B);
+  memcpy(out->a, &Aa, 64);
+  memcpy(out->b, &Ba, 128);
+  memcpy(out->c, &Ca, 64);
+  return ZG16_OK;
+}
+
+zg16_status zg16_prove(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1cs* r, const uint64_t* z_in, const uint64_t* z_aux,
+                       int on_device, const uint64_t r_[4], const uint64_t s_[4], zg16_proof* out) {
+  if (!ctx || !pk) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "bad arguments to zg16_prove");
+  if (pk->shard_count != 1) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "zg16_prove needs an unsharded key");
+  if (pk->delta_g1.is_inf() || pk->delta_g2.is_inf())
+    return fail(ctx, ZG16_ERR_UNEXPECTED_IDENTITY, "delta is the point at infinity");
+  zg16_partial part;
+  ZG_TRY(zg16_prove_partial(ctx, pk, r, z_in, z_aux, on_device, &part));
+  zg16_pk_view v = {};
+  v.alpha_g1 = (const uint64_t*)&pk->alpha_g1;
+  v.beta_g1 = (const uint64_t*)&pk->beta_g1;
+  v.beta_g2 = (const uint64_t*)&pk->beta_g2;
+  v.delta_g1 = (const uint64_t*)&pk->delta_g1;
+  v.delta_g2 = (const uint64_t*)&pk->delta_g2;
+  auto t0 = std::chrono::steady_clock::now();
+  zg16_status st = zg16_prove_finish(&v, &part, 1, r_, s_, out);
+  ctx->timings.finish_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  ctx->timings.total_ms += ctx->timings.finish_ms;
+  if (st != ZG16_OK) return fail(ctx, st, "final assembly failed");
+  return ZG16_OK;
+}
+
+zg16_status zg16_last_timings(const zg16_ctx* ctx, zg16_timings* out) {
+  if (!ctx || !out) return ZG16_ERR_INVALID_ARGUMENT;
+  *out = ctx->timings;
+  return ZG16_OK;
+}
+
+// ---------------------------------------------------------------------------- stand-alone stages
+zg16_status zg16_ntt(zg16_ctx* ctx, uint64_t* data, unsigned log_n, int inverse, int coset, int on_device) {
+  if (!ctx || !data) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "bad arguments to zg16_ntt");
+  if (log_n >= 28) return fail(ctx, ZG16_ERR_POLYNOMIAL_DEGREE_TOO_LARGE, "domain 2^%u exceeds 2^27", log_n);
+  ZG_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t bytes = sizeof(Fr) << log_n;
+  Fr* d = (Fr*)data;
+  if (!on_device) {
+    ZG_TRY(scratch_get(ctx, 4, bytes, (void**)&d));
+    ZG_HIP(ctx, hipMemcpyAsync(d, data, bytes, hipMemcpyHostToDevice, ctx->stream));
+  }
+  ZG_TRY(ntt_device(ctx, d, log_n, inverse != 0, coset != 0));
+  if (!on_device) ZG_HIP(ctx, hipMemcpyAsync(data, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ZG16_OK;
+}
+
+zg16_status zg16_h_coefficients(zg16_ctx* ctx, const uint64_t* a, const uint64_t* b, const uint64_t* c, size_t n_rows,
+                                uint64_t* h, size_t* m_out) {
+  if (!ctx || !a || !b || !c || !h || !n_rows) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "bad arguments to zg16_h_coefficients");
+  const unsigned log_m = ceil_log2(n_rows);
+  if (log_m >= 28) return fail(ctx, ZG16_ERR_POLYNOMIAL_DEGREE_TOO_LARGE, "%zu rows need a domain of 2^%u", n_rows, log_m);
+  ZG_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t m = (size_t)1 << log_m;
+  Fr* abc;
+  ZG_TRY(scratch_get(ctx, 4, 3 * m * sizeof(Fr), (void**)&abc));
+  const uint64_t* src[3] = {a, b, c};
+  for (int k = 0; k < 3; k++) {
+    ZG_HIP(ctx, hipMemcpyAsync(abc + k * m, src[k], n_rows * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    if (m > n_rows) ZG_HIP(ctx, hipMemsetAsync(abc + k * m + n_rows, 0, (m - n_rows) * sizeof(Fr), ctx->stream));
+  }
+  ZG_TRY(h_pipeline_device(ctx, abc, abc + m, abc + 2 * m, log_m));
+  if (m > 1) ZG_HIP(ctx, hipMemcpyAsync(h, abc, (m - 1) * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+  ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (m_out) *m_out = m;
+  return ZG16_OK;
+}
+
+zg16_status zg16_msm_g1(zg16_ctx* ctx, const uint64_t* bases, size_t n_bases, const uint64_t* scalars, size_t n_scalars,
+                        const uint8_t* density, uint64_t out[8]) {
+  G1Affine res;
+  zg16_status st = msm_entry<Fq>(ctx, bases, n_bases, scalars, n_scalars, density, &res, msm_g1_device);
+  if (st == ZG16_OK) memcpy(out, &res, 64);
+  return st;
+}
+
+zg16_status zg16_msm_g2(zg16_ctx* ctx, const uint64_t* bases, size_t n_bases, const uint64_t* scalars, size_t n_scalars,
+                        const uint8_t* density, uint64_t out[16]) {
+  G2Affine res;
+  zg16_status st = msm_entry<Fq2>(ctx, bases, n_bases, scalars, n_scalars, density, &res, msm_g2_device);
+  if (st == ZG16_OK) memcpy(out, &res, 128);
+  return st;
+}
+
+zg16_status zg16_spmv(zg16_ctx* ctx, const zg16_r1cs* r, const uint64_t* z_in, const uint64_t* z_aux, uint64_t* a,
+                      uint64_t* b, uint64_t* c) {
+  if (!ctx || !r || !a || !b || !c) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "bad arguments to zg16_spmv");
+  ZG_HIP(ctx, hipSetDevice(ctx->device));
+  Fr* z;
+  ZG_TRY(stage_witness(ctx, r, z_in, z_aux, 0, &z));
+  Fr* abc;
+  const size_t n = r->n_rows;
+  ZG_TRY(scratch_get(ctx, 4, 3 * n * sizeof(Fr) + 32, (void**)&abc));
+  ZG_TRY(spmv_device(ctx, r, z, abc, abc + n, abc + 2 * n));
+  uint64_t* outs[3] = {a, b, c};
+  for (int k = 0; k < 3; k++)
+    if (n) ZG_HIP(ctx, hipMemcpyAsync(outs[k], abc + k * n, n * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+  ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ZG16_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,110 @@
+// Internal plumbing shared by the library's translation units: the context object, error
+// capture, device-buffer helpers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/zinc_groth16.h"
+#include "curve.cuh"
+
+namespace zg {
+
+struct NttDomain;   // ntt.hip
+struct MsmScratch;  // msm.hip
+
+}  // namespace zg
+
+struct zg16_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;      // stream all kernels are issued on
+  hipStream_t own_stream = nullptr;  // created by the context
+  hipStream_t aux_stream = nullptr;  // second stream for overlapping independent stages
+  hipEvent_t ev[8] = {};
+  std::string last_error = "";
+  std::map<unsigned, zg::NttDomain*> domains;  // per log2 size
+  zg::MsmScratch* msm_scratch[2] = {nullptr, nullptr};
+  // grow-only device scratch arenas, one per independent consumer
+  void* scratch[6] = {};
+  size_t scratch_bytes[6] = {};
+  zg16_timings timings = {};
+};
+
+namespace zg {
+
+inline zg16_status fail(zg16_ctx* ctx, zg16_status st, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->last_error = buf;
+  return st;
+}
+
+#define ZG_HIP(ctx, call)                                                                     \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess)                                                                     \
+      return zg::fail(ctx, e_ == hipErrorOutOfMemory ? ZG16_ERR_OUT_OF_MEMORY : ZG16_ERR_DEVICE, \
+                      "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+#define ZG_TRY(expr)                   \
+  do {                                 \
+    zg16_status s_ = (expr);           \
+    if (s_ != ZG16_OK) return s_;      \
+  } while (0)
+
+// Grow-only scratch arena `slot` of at least `bytes`.
+inline zg16_status scratch_get(zg16_ctx* ctx, int slot, size_t bytes, void** out) {
+  if (ctx->scratch_bytes[slot] < bytes) {
+    if (ctx->scratch[slot]) {
+      ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      ZG_HIP(ctx, hipFree(ctx->scratch[slot]));
+      ctx->scratch[slot] = nullptr;
+      ctx->scratch_bytes[slot] = 0;
+    }
+    size_t want = bytes + bytes / 8;
+    ZG_HIP(ctx, hipMalloc(&ctx->scratch[slot], want));
+    ctx->scratch_bytes[slot] = want;
+  }
+  *out = ctx->scratch[slot];
+  return ZG16_OK;
+}
+
+static inline unsigned ceil_log2(size_t n) {
+  unsigned l = 0;
+  while (((size_t)1 << l) < n) l++;
+  return l;
+}
+
+// ---- stage entry points implemented in the other translation units -------------------------
+// NTT of 2^log_n device-resident elements, natural order in and out.  `data` is overwritten.
+// inverse: use omega^-1 and scale by 1/m.  coset: coset_fft (pre-scale by g^i) or icoset_fft
+// (post-scale by g^-i).
+zg16_status ntt_device(zg16_ctx* ctx, Fr* data, unsigned log_n, bool inverse, bool coset);
+// a, b, c: device arrays of 2^log_m elements (zero-padded row evaluations); on return `a` holds
+// the icoset_fft output whose first m-1 entries are the H coefficients.  b, c are clobbered.
+zg16_status h_pipeline_device(zg16_ctx* ctx, Fr* a, Fr* b, Fr* c, unsigned log_m);
+
+// One multiexp term list: result += sum_k scalar(k) * bases[k], k < n, where
+// scalar(k) = scalars[index ? index[k] : k] (Montgomery Fr, device memory).
+template <class F>
+struct MsmJob {
+  const Affine<F>* bases;
+  const Fr* scalars;
+  const uint32_t* index;  // optional gather map into scalars
+  size_t n;
+};
+// Sum of several jobs as one multiexp; writes one XYZZ point to host memory `out`.
+zg16_status msm_g1_device(zg16_ctx* ctx, const MsmJob<Fq>* jobs, int njobs, G1XYZZ* out_host);
+zg16_status msm_g2_device(zg16_ctx* ctx, const MsmJob<Fq2>* jobs, int njobs, G2XYZZ* out_host);
+
+void ntt_free_domains(zg16_ctx* ctx);
+void msm_free_scratch(zg16_ctx* ctx);
+
+}  // namespace zg

@@ -1,0 +1,309 @@
+// BN254 prime fields in Montgomery form (R = 2^256) for host and gfx950 device code.
+//
+// Memory layout of one element is 8 little-endian u32 limbs = the 4 x u64 little-endian
+// Montgomery limbs that ff_ce 0.6.0 keeps in memory (Cargo.lock:1363-1366 of the reference pins
+// it), so a Rust `&[Fr]` can be handed to the kernels without conversion.
+//
+// The multiplier is an 8 x 32-bit CIOS loop: the only wide integer multiply the CDNA4 VALU has
+// is v_mad_u64_u32 (32 x 32 + 64 -> 64), so 32-bit limbs are the native digit size; each
+// `(uint64_t)a * b + c` below is written so that it lowers to exactly one of them.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define ZG_HD __host__ __device__ __forceinline__
+#define ZG_D __device__ __forceinline__
+#else
+#define ZG_HD inline
+#define ZG_D inline
+#endif
+
+namespace zg {
+
+struct FrParams {
+  // r = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+  ZG_HD static constexpr uint32_t mod(int i) {
+    constexpr uint32_t m[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u,
+                               0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+    return m[i];
+  }
+  // R mod r  (Montgomery form of 1)
+  ZG_HD static constexpr uint32_t one(int i) {
+    constexpr uint32_t m[8] = {0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u,
+                               0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+    return m[i];
+  }
+  // R^2 mod r
+  ZG_HD static constexpr uint32_t r2(int i) {
+    constexpr uint32_t m[8] = {0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u,
+                               0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u};
+    return m[i];
+  }
+  static constexpr uint32_t inv = 0xefffffffu;  // -r^-1 mod 2^32
+};
+
+struct FqParams {
+  // q = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+  ZG_HD static constexpr uint32_t mod(int i) {
+    constexpr uint32_t m[8] = {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u,
+                               0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+    return m[i];
+  }
+  ZG_HD static constexpr uint32_t one(int i) {
+    constexpr uint32_t m[8] = {0xc58f0d9du, 0xd35d438du, 0xf5c70b3du, 0x0a78eb28u,
+                               0x7879462cu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+    return m[i];
+  }
+  ZG_HD static constexpr uint32_t r2(int i) {
+    constexpr uint32_t m[8] = {0x538afa89u, 0xf32cfc5bu, 0xd44501fbu, 0xb5e71911u,
+                               0x0a417ff6u, 0x47ab1effu, 0xcab8351fu, 0x06d89f71u};
+    return m[i];
+  }
+  static constexpr uint32_t inv = 0xe4866389u;  // -q^-1 mod 2^32
+};
+
+template <class P>
+struct alignas(16) Fp {
+  uint32_t v[8];
+
+  ZG_HD static Fp zero() {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = 0;
+    return r;
+  }
+  ZG_HD static Fp one() {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = P::one(i);
+    return r;
+  }
+  ZG_HD bool is_zero() const {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o |= v[i];
+    return o == 0;
+  }
+  ZG_HD bool operator==(const Fp& b) const {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o |= v[i] ^ b.v[i];
+    return o == 0;
+  }
+  ZG_HD bool operator!=(const Fp& b) const { return !(*this == b); }
+};
+
+// r = a - mod if a >= mod else a   (a < 2*mod < 2^256)
+template <class P>
+ZG_HD void reduce_once(uint32_t* a) {
+  uint32_t d[8];
+  uint64_t borrow = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    uint64_t t = (uint64_t)a[i] - P::mod(i) - borrow;
+    d[i] = (uint32_t)t;
+    borrow = (t >> 32) & 1;
+  }
+  if (!borrow) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) a[i] = d[i];
+  }
+}
+
+template <class P>
+ZG_HD Fp<P> add(const Fp<P>& a, const Fp<P>& b) {
+  Fp<P> r;
+  uint64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    c += (uint64_t)a.v[i] + b.v[i];
+    r.v[i] = (uint32_t)c;
+    c >>= 32;
+  }
+  reduce_once<P>(r.v);  // a + b < 2*mod < 2^255: no carry out of limb 7
+  return r;
+}
+
+template <class P>
+ZG_HD Fp<P> sub(const Fp<P>& a, const Fp<P>& b) {
+  Fp<P> r;
+  uint64_t borrow = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    uint64_t t = (uint64_t)a.v[i] - b.v[i] - borrow;
+    r.v[i] = (uint32_t)t;
+    borrow = (t >> 32) & 1;
+  }
+  uint32_t mask = (uint32_t)0 - (uint32_t)borrow;
+  uint64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    c += (uint64_t)r.v[i] + (P::mod(i) & mask);
+    r.v[i] = (uint32_t)c;
+    c >>= 32;
+  }
+  return r;
+}
+
+template <class P>
+ZG_HD Fp<P> neg(const Fp<P>& a) {
+  return a.is_zero() ? a : sub(Fp<P>::zero(), a);
+}
+
+template <class P>
+ZG_HD Fp<P> dbl(const Fp<P>& a) {
+  return add(a, a);
+}
+
+// Montgomery product a*b*R^-1 mod p, CIOS over 32-bit digits.  Because p < 2^254 the running
+// value stays below 2p + epsilon, so one spare limb (t[8]) is enough.
+template <class P>
+ZG_HD Fp<P> mul(const Fp<P>& a, const Fp<P>& b) {
+  uint32_t t[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) t[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    uint64_t c = 0;
+    const uint32_t bi = b.v[i];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      c += (uint64_t)a.v[j] * bi + t[j];
+      t[j] = (uint32_t)c;
+      c >>= 32;
+    }
+    c += t[8];
+    t[8] = (uint32_t)c;  // bits above 2^288 cannot occur
+    const uint32_t m = t[0] * P::inv;
+    c = (uint64_t)m * P::mod(0) + t[0];
+    c >>= 32;
+#pragma unroll
+    for (int j = 1; j < 8; j++) {
+      c += (uint64_t)m * P::mod(j) + t[j];
+      t[j - 1] = (uint32_t)c;
+      c >>= 32;
+    }
+    c += t[8];
+    t[7] = (uint32_t)c;
+    t[8] = (uint32_t)(c >> 32);
+  }
+  reduce_once<P>(t);
+  Fp<P> r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = t[i];
+  return r;
+}
+
+template <class P>
+ZG_HD Fp<P> sqr(const Fp<P>& a) {
+  return mul(a, a);
+}
+
+// Montgomery form -> canonical integer (multiply by 1).
+template <class P>
+ZG_HD Fp<P> from_mont(const Fp<P>& a) {
+  Fp<P> o = Fp<P>::zero();
+  o.v[0] = 1;
+  return mul(a, o);
+}
+
+template <class P>
+ZG_HD Fp<P> to_mont(const Fp<P>& a) {
+  Fp<P> r2;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r2.v[i] = P::r2(i);
+  return mul(a, r2);
+}
+
+// a^e for a little-endian u32 exponent of `nlimbs` limbs (square and multiply, MSB first).
+template <class P>
+ZG_HD Fp<P> pow_limbs(const Fp<P>& a, const uint32_t* e, int nlimbs) {
+  Fp<P> r = Fp<P>::one();
+  bool started = false;
+  for (int i = nlimbs - 1; i >= 0; i--) {
+    for (int b = 31; b >= 0; b--) {
+      if (started) r = sqr(r);
+      if ((e[i] >> b) & 1) {
+        r = started ? mul(r, a) : a;
+        started = true;
+      }
+    }
+  }
+  return r;
+}
+
+// a^-1 by Fermat (a != 0); used for one-off host-side and per-launch scalars only.
+template <class P>
+ZG_HD Fp<P> inv(const Fp<P>& a) {
+  uint32_t e[8];
+  uint64_t borrow = 2;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    uint64_t t = (uint64_t)P::mod(i) - borrow;
+    e[i] = (uint32_t)t;
+    borrow = (t >> 32) & 1;
+  }
+  return pow_limbs(a, e, 8);
+}
+
+template <class P>
+ZG_HD Fp<P> pow_u64(const Fp<P>& a, uint64_t e) {
+  uint32_t l[2] = {(uint32_t)e, (uint32_t)(e >> 32)};
+  return pow_limbs(a, l, 2);
+}
+
+template <class P>
+ZG_HD Fp<P> from_u64(uint64_t x) {
+  Fp<P> r = Fp<P>::zero();
+  r.v[0] = (uint32_t)x;
+  r.v[1] = (uint32_t)(x >> 32);
+  return to_mont(r);
+}
+
+// canonical comparison helper: is a (any residue representative < 2^256) below the modulus?
+template <class P>
+ZG_HD bool is_canonical(const uint32_t* a) {
+  for (int i = 7; i >= 0; i--) {
+    if (a[i] < P::mod(i)) return true;
+    if (a[i] > P::mod(i)) return false;
+  }
+  return false;
+}
+
+using Fr = Fp<FrParams>;
+using Fq = Fp<FqParams>;
+
+// ------------------------------------------------------------------ Fq2 = Fq[u]/(u^2+1)
+struct Fq2 {
+  Fq c0, c1;
+  ZG_HD static Fq2 zero() { return {Fq::zero(), Fq::zero()}; }
+  ZG_HD static Fq2 one() { return {Fq::one(), Fq::zero()}; }
+  ZG_HD bool is_zero() const { return c0.is_zero() && c1.is_zero(); }
+  ZG_HD bool operator==(const Fq2& b) const { return c0 == b.c0 && c1 == b.c1; }
+  ZG_HD bool operator!=(const Fq2& b) const { return !(*this == b); }
+};
+
+ZG_HD Fq2 add(const Fq2& a, const Fq2& b) { return {add(a.c0, b.c0), add(a.c1, b.c1)}; }
+ZG_HD Fq2 sub(const Fq2& a, const Fq2& b) { return {sub(a.c0, b.c0), sub(a.c1, b.c1)}; }
+ZG_HD Fq2 neg(const Fq2& a) { return {neg(a.c0), neg(a.c1)}; }
+ZG_HD Fq2 dbl(const Fq2& a) { return {dbl(a.c0), dbl(a.c1)}; }
+// Karatsuba: 3 base-field products
+ZG_HD Fq2 mul(const Fq2& a, const Fq2& b) {
+  Fq aa = mul(a.c0, b.c0);
+  Fq bb = mul(a.c1, b.c1);
+  Fq s = mul(add(a.c0, a.c1), add(b.c0, b.c1));
+  return {sub(aa, bb), sub(sub(s, aa), bb)};
+}
+// (c0 + c1 u)^2 = (c0+c1)(c0-c1) + 2 c0 c1 u : 2 base-field products
+ZG_HD Fq2 sqr(const Fq2& a) {
+  Fq p = mul(add(a.c0, a.c1), sub(a.c0, a.c1));
+  Fq m = mul(a.c0, a.c1);
+  return {p, dbl(m)};
+}
+ZG_HD Fq2 inv(const Fq2& a) {
+  Fq n = inv(add(sqr(a.c0), sqr(a.c1)));
+  return {mul(a.c0, n), neg(mul(a.c1, n))};
+}
+
+}  // namespace zg

@@ -1,0 +1,336 @@
+"""Host-side mirror of the bellman Groth16 prover interface that zinc-vm uses.
+
+zinc-vm builds a `bellman::Circuit`, and bellman drives `Circuit::synthesize(&mut cs)` against
+its own `ProvingAssignment` before running the FFT / multiexp stages
+(zinc-vm/src/core/circuit/facade.rs:145-153, zinc-vm/src/core/circuit/synthesizer.rs:33-38).
+This module keeps those names and meanings -- `ProvingAssignment.alloc / alloc_input / enforce`,
+`create_proof(circuit, params, r, s)`, `create_random_proof(circuit, params, rng)`,
+`SynthesisError` variants -- but the assignment only records; all arithmetic after synthesis runs
+in the HIP library through the C ABI (include/zinc_groth16.h).
+"""
+import ctypes as C
+import secrets
+
+import numpy as np
+
+from . import lib as _lib
+from .fields import R_MOD, MONT_R, ints_to_mont, mont_to_ints, g1_to_mont, g2_to_mont, mont_to_g1, mont_to_g2
+
+AUX = 1 << 31
+
+
+class SynthesisError(_lib.Groth16Error):
+    """Failure reported by the prover backend; `.status_name` is the bellman variant name."""
+
+
+def _check(ctx_handle, status):
+    if status != _lib.OK:
+        msg = _lib.load().zg16_last_error(ctx_handle).decode() if ctx_handle else ""
+        raise SynthesisError(status, msg)
+
+
+class Context:
+    """One GPU: streams, scratch memory, cached NTT tables."""
+
+    def __init__(self, device=0):
+        self._lib = _lib.load()
+        self.handle = C.c_void_p()
+        st = self._lib.zg16_ctx_create(device, C.byref(self.handle))
+        if st != _lib.OK:
+            raise SynthesisError(st, "cannot create a context on GPU %d (is an MI355X visible?)" % device)
+        self.device = device
+
+    def close(self):
+        if self.handle:
+            self._lib.zg16_ctx_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream):
+        _check(self.handle, self._lib.zg16_ctx_set_stream(self.handle, C.c_void_p(hip_stream)))
+
+    def timings(self):
+        t = _lib.Timings()
+        _check(self.handle, self._lib.zg16_last_timings(self.handle, C.byref(t)))
+        return {n: getattr(t, n) for n, _ in t._fields_}
+
+    # ---- stand-alone stages -------------------------------------------------------------
+    def ntt(self, data, inverse=False, coset=False):
+        """data: (2^k, 4) uint64 Montgomery Fr; returns the transformed copy."""
+        arr = np.ascontiguousarray(data, dtype=np.uint64).reshape(-1, 4).copy()
+        n = arr.shape[0]
+        log_n = n.bit_length() - 1
+        assert 1 << log_n == n
+        _check(self.handle, self._lib.zg16_ntt(self.handle, arr.ctypes.data_as(C.c_void_p), log_n,
+                                               int(inverse), int(coset), 0))
+        return arr
+
+    def h_coefficients(self, a, b, c):
+        a, b, c = (np.ascontiguousarray(x, dtype=np.uint64).reshape(-1, 4) for x in (a, b, c))
+        n_rows = a.shape[0]
+        m = 1
+        while m < n_rows:
+            m *= 2
+        h = np.zeros((max(m - 1, 1), 4), dtype=np.uint64)
+        m_out = C.c_size_t()
+        _check(self.handle, self._lib.zg16_h_coefficients(self.handle, _lib.as_u64p(a), _lib.as_u64p(b),
+                                                          _lib.as_u64p(c), n_rows, _lib.as_u64p(h), C.byref(m_out)))
+        return h[:m - 1], m_out.value
+
+    def _msm(self, fn, width, bases, scalars, density):
+        bases = np.ascontiguousarray(bases, dtype=np.uint64).reshape(-1, width)
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+        out = np.zeros(width, dtype=np.uint64)
+        dptr = None
+        if density is not None:
+            density = np.ascontiguousarray(density, dtype=np.uint8)
+            assert density.shape[0] == scalars.shape[0]
+            dptr = density.ctypes.data_as(_lib.u8p)
+        # empty arrays still need a valid pointer type
+        bp = _lib.as_u64p(bases) if bases.size else None
+        sp = _lib.as_u64p(scalars) if scalars.size else None
+        _check(self.handle, fn(self.handle, bp, bases.shape[0], sp, scalars.shape[0], dptr, _lib.as_u64p(out)))
+        return out
+
+    def msm_g1(self, bases, scalars, density=None):
+        return self._msm(self._lib.zg16_msm_g1, 8, bases, scalars, density)
+
+    def msm_g2(self, bases, scalars, density=None):
+        return self._msm(self._lib.zg16_msm_g2, 16, bases, scalars, density)
+
+
+class Proof:
+    """bellman `Proof<Bn256>`: three affine points, here as canonical integers."""
+
+    def __init__(self, raw):
+        self.raw = raw
+        self.a = mont_to_g1(np.frombuffer(bytes(raw.a), dtype=np.uint64))[0]
+        self.b = mont_to_g2(np.frombuffer(bytes(raw.b), dtype=np.uint64))[0]
+        self.c = mont_to_g1(np.frombuffer(bytes(raw.c), dtype=np.uint64))[0]
+
+    def as_tuple(self):
+        return (self.a, self.b, self.c)
+
+
+class Parameters:
+    """bellman `Parameters<Bn256>` as Montgomery limb arrays (what the ABI takes)."""
+
+    def __init__(self, alpha_g1, beta_g1, beta_g2, delta_g1, delta_g2, h, l, a, b_g1, b_g2):
+        f = lambda x, w: np.ascontiguousarray(x, dtype=np.uint64).reshape(-1, w)
+        self.alpha_g1, self.beta_g1, self.delta_g1 = f(alpha_g1, 8), f(beta_g1, 8), f(delta_g1, 8)
+        self.beta_g2, self.delta_g2 = f(beta_g2, 16), f(delta_g2, 16)
+        self.h, self.l, self.a, self.b_g1 = f(h, 8), f(l, 8), f(a, 8), f(b_g1, 8)
+        self.b_g2 = f(b_g2, 16)
+
+    @classmethod
+    def from_points(cls, pk):
+        """pk: any object with bellman's field names holding affine integer points."""
+        return cls(g1_to_mont([pk.alpha_g1]), g1_to_mont([pk.beta_g1]), g2_to_mont([pk.beta_g2]),
+                   g1_to_mont([pk.delta_g1]), g2_to_mont([pk.delta_g2]), g1_to_mont(pk.h),
+                   g1_to_mont(pk.l), g1_to_mont(pk.a), g1_to_mont(pk.b_g1), g2_to_mont(pk.b_g2))
+
+    def view(self):
+        v = _lib.PkView()
+        p = lambda a: _lib.as_u64p(a) if a.size else None
+        v.alpha_g1, v.beta_g1, v.beta_g2 = p(self.alpha_g1), p(self.beta_g1), p(self.beta_g2)
+        v.delta_g1, v.delta_g2 = p(self.delta_g1), p(self.delta_g2)
+        v.h, v.n_h = p(self.h), self.h.shape[0]
+        v.l, v.n_l = p(self.l), self.l.shape[0]
+        v.a, v.n_a = p(self.a), self.a.shape[0]
+        v.b_g1, v.n_b_g1 = p(self.b_g1), self.b_g1.shape[0]
+        v.b_g2, v.n_b_g2 = p(self.b_g2), self.b_g2.shape[0]
+        return v
+
+    def upload(self, ctx, shard_index=0, shard_count=1):
+        return DeviceKey(ctx, self, shard_index, shard_count)
+
+
+class DeviceKey:
+    def __init__(self, ctx, params, shard_index=0, shard_count=1):
+        self.ctx, self.params = ctx, params
+        self.handle = C.c_void_p()
+        v = params.view()
+        _check(ctx.handle, ctx._lib.zg16_pk_upload(ctx.handle, C.byref(v), shard_index, shard_count,
+                                                   C.byref(self.handle)))
+
+    def free(self):
+        if self.handle:
+            self.ctx._lib.zg16_pk_free(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class R1CS:
+    """Recorded constraint matrices (CSR) ready for upload; rows include bellman's input rows."""
+
+    def __init__(self, n_inputs, n_aux, mats):
+        """mats: three (row_ptr uint64[n_rows+1], col uint32[nnz], coeff uint64[nnz,4]) triples."""
+        self.n_inputs, self.n_aux = n_inputs, n_aux
+        self.mats = [(np.ascontiguousarray(rp, dtype=np.uint64), np.ascontiguousarray(col, dtype=np.uint32),
+                      np.ascontiguousarray(co, dtype=np.uint64).reshape(-1, 4)) for rp, col, co in mats]
+        self.n_rows = self.mats[0][0].shape[0] - 1
+
+    def view(self):
+        v = _lib.R1csView()
+        v.n_rows, v.n_inputs, v.n_aux = self.n_rows, self.n_inputs, self.n_aux
+        for name, (rp, col, co) in zip("abc", self.mats):
+            csr = _lib.Csr()
+            csr.row_ptr = _lib.as_u64p(rp)
+            csr.col = _lib.as_u32p(col) if col.size else None
+            csr.coeff = _lib.as_u64p(co) if co.size else None
+            setattr(v, name, csr)
+        return v
+
+    def upload(self, ctx):
+        return DeviceR1CS(ctx, self)
+
+
+class DeviceR1CS:
+    def __init__(self, ctx, r1cs):
+        self.ctx, self.r1cs = ctx, r1cs
+        self.handle = C.c_void_p()
+        v = r1cs.view()
+        _check(ctx.handle, ctx._lib.zg16_r1cs_upload(ctx.handle, C.byref(v), C.byref(self.handle)))
+
+    def density(self):
+        a, bi, ba = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        _check(self.ctx.handle, self.ctx._lib.zg16_r1cs_density(self.handle, C.byref(a), C.byref(bi), C.byref(ba)))
+        return a.value, bi.value, ba.value
+
+    def spmv(self, z_in, z_aux):
+        n = self.r1cs.n_rows
+        outs = [np.zeros((n, 4), dtype=np.uint64) for _ in range(3)]
+        zi = np.ascontiguousarray(z_in, dtype=np.uint64).reshape(-1, 4)
+        za = np.ascontiguousarray(z_aux, dtype=np.uint64).reshape(-1, 4)
+        _check(self.ctx.handle, self.ctx._lib.zg16_spmv(
+            self.ctx.handle, self.handle, _lib.as_u64p(zi), _lib.as_u64p(za) if za.size else None,
+            *[_lib.as_u64p(o) for o in outs]))
+        return outs
+
+    def free(self):
+        if self.handle:
+            self.ctx._lib.zg16_r1cs_free(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class ProvingAssignment:
+    """Recording constraint system with the call surface of bellman's ProvingAssignment.
+
+    Unlike upstream it does not evaluate rows while synthesizing: it records the three matrices
+    in CSR form and the witness, and the GPU evaluates A z, B z, C z.  Linear combinations are
+    lists of (variable, coefficient) with canonical integer coefficients; they must already be in
+    the canonical form zinc-vm's Dedup wrapper produces (zinc-vm/src/constraint_systems/dedup.rs:50-68).
+    """
+
+    def __init__(self):
+        self.z_in, self.z_aux = [], []
+        self._rp = ([0], [0], [0])
+        self._col = ([], [], [])
+        self._coeff = ([], [], [])
+
+    @staticmethod
+    def one():
+        return 0
+
+    def alloc_input(self, value):
+        if value is None:
+            raise SynthesisError(3, "alloc_input without a value")
+        self.z_in.append(int(value) % R_MOD)
+        return len(self.z_in) - 1
+
+    def alloc(self, value):
+        if value is None:
+            raise SynthesisError(3, "alloc without a value")
+        self.z_aux.append(int(value) % R_MOD)
+        return (len(self.z_aux) - 1) | AUX
+
+    def enforce(self, a_lc, b_lc, c_lc):
+        for k, lc in enumerate((a_lc, b_lc, c_lc)):
+            for col, coeff in lc:
+                self._col[k].append(col)
+                self._coeff[k].append(int(coeff) % R_MOD)
+            self._rp[k].append(len(self._col[k]))
+
+    def finalize_inputs(self):
+        for i in range(len(self.z_in)):
+            self.enforce([(i, 1)], [], [])
+
+    def r1cs(self):
+        mats = []
+        for k in range(3):
+            co = ints_to_mont(self._coeff[k], R_MOD) if self._coeff[k] else np.zeros((0, 4), dtype=np.uint64)
+            mats.append((np.array(self._rp[k], dtype=np.uint64), np.array(self._col[k], dtype=np.uint32), co))
+        return R1CS(len(self.z_in), len(self.z_aux), mats)
+
+    def witness(self):
+        zi = ints_to_mont(self.z_in, R_MOD)
+        za = ints_to_mont(self.z_aux, R_MOD) if self.z_aux else np.zeros((0, 4), dtype=np.uint64)
+        return zi, za
+
+
+def prove_recorded(ctx, dev_key, dev_r1cs, z_in, z_aux, r_mont, s_mont):
+    """zg16_prove on uploaded handles; z_in/z_aux/r/s are Montgomery limb arrays."""
+    raw = _lib.Proof()
+    zi = np.ascontiguousarray(z_in, dtype=np.uint64).reshape(-1, 4)
+    za = np.ascontiguousarray(z_aux, dtype=np.uint64).reshape(-1, 4)
+    r_mont = np.ascontiguousarray(r_mont, dtype=np.uint64).reshape(4)
+    s_mont = np.ascontiguousarray(s_mont, dtype=np.uint64).reshape(4)
+    _check(ctx.handle, ctx._lib.zg16_prove(
+        ctx.handle, dev_key.handle, dev_r1cs.handle, zi.ctypes.data_as(C.c_void_p),
+        za.ctypes.data_as(C.c_void_p) if za.size else None, 0, _lib.as_u64p(r_mont), _lib.as_u64p(s_mont),
+        C.byref(raw)))
+    return Proof(raw)
+
+
+def create_proof(circuit, params, r, s, ctx=None):
+    """bellman `create_proof(circuit, params, r, s)`; r, s are canonical integers in Fr."""
+    ctx = ctx or Context()
+    pa = ProvingAssignment()
+    pa.alloc_input(1)
+    circuit.synthesize(pa)
+    pa.finalize_inputs()
+    key = params.upload(ctx)
+    mat = pa.r1cs().upload(ctx)
+    zi, za = pa.witness()
+    rs = ints_to_mont([r, s], R_MOD)
+    try:
+        return prove_recorded(ctx, key, mat, zi, za, rs[0], rs[1])
+    finally:
+        key.free()
+        mat.free()
+
+
+def random_fr(rng=None):
+    """ff_ce's `Fr::rand`: 4 x u64, clear the top two bits, retry until below r.  The pattern
+    drawn is the Montgomery representation (returned as the canonical value it stands for)."""
+    while True:
+        raw = 0
+        for i in range(4):
+            limb = rng.next_u64() if rng is not None else secrets.randbits(64)
+            raw |= limb << (64 * i)
+        raw &= (1 << 254) - 1
+        if raw < R_MOD:
+            return raw * pow(MONT_R, -1, R_MOD) % R_MOD
+
+
+def create_random_proof(circuit, params, rng=None, ctx=None):
+    """bellman `create_random_proof`: r then s drawn from rng (zinc-vm/src/core/circuit/facade.rs:140-153)."""
+    r = random_fr(rng)
+    s = random_fr(rng)
+    return create_proof(circuit, params, r, s, ctx)

@@ -1,0 +1,121 @@
+"""ctypes binding of libzinc_groth16_hip.so (the C ABI in include/zinc_groth16.h).
+
+There is no CPU fallback: if the HIP library has not been built, importing symbols from here
+raises, and every entry point needs a visible MI355X.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libzinc_groth16_hip.so")
+
+OK = 0
+STATUS_NAMES = {
+    0: "OK",
+    1: "PolynomialDegreeTooLarge",
+    2: "UnexpectedIdentity",
+    3: "AssignmentMissing",
+    4: "MalformedKey",
+    5: "InvalidArgument",
+    6: "DeviceError",
+    7: "OutOfMemory",
+}
+
+u64p = C.POINTER(C.c_uint64)
+u32p = C.POINTER(C.c_uint32)
+u8p = C.POINTER(C.c_uint8)
+
+
+class PkView(C.Structure):
+    _fields_ = [("alpha_g1", u64p), ("beta_g1", u64p), ("beta_g2", u64p), ("delta_g1", u64p),
+                ("delta_g2", u64p),
+                ("h", u64p), ("n_h", C.c_size_t), ("l", u64p), ("n_l", C.c_size_t),
+                ("a", u64p), ("n_a", C.c_size_t), ("b_g1", u64p), ("n_b_g1", C.c_size_t),
+                ("b_g2", u64p), ("n_b_g2", C.c_size_t)]
+
+
+class Csr(C.Structure):
+    _fields_ = [("row_ptr", u64p), ("col", u32p), ("coeff", u64p)]
+
+
+class R1csView(C.Structure):
+    _fields_ = [("n_rows", C.c_size_t), ("n_inputs", C.c_size_t), ("n_aux", C.c_size_t),
+                ("a", Csr), ("b", Csr), ("c", Csr)]
+
+
+class Proof(C.Structure):
+    _fields_ = [("a", C.c_uint64 * 8), ("b", C.c_uint64 * 16), ("c", C.c_uint64 * 8)]
+
+
+class Partial(C.Structure):
+    _fields_ = [("hl", C.c_uint64 * 16), ("a", C.c_uint64 * 16), ("b1", C.c_uint64 * 16),
+                ("b2", C.c_uint64 * 32)]
+
+
+class Timings(C.Structure):
+    _fields_ = [(n, C.c_float) for n in
+                ("upload_ms", "spmv_ms", "ntt_ms", "msm_g1_ms", "msm_g2_ms", "finish_ms", "total_ms")]
+
+
+# every symbol include/zinc_groth16.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("zg16_ctx_create", C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    ("zg16_ctx_destroy", None, [C.c_void_p]),
+    ("zg16_last_error", C.c_char_p, [C.c_void_p]),
+    ("zg16_ctx_set_stream", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("zg16_pk_upload", C.c_int, [C.c_void_p, C.POINTER(PkView), C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    ("zg16_pk_free", None, [C.c_void_p]),
+    ("zg16_r1cs_upload", C.c_int, [C.c_void_p, C.POINTER(R1csView), C.POINTER(C.c_void_p)]),
+    ("zg16_r1cs_free", None, [C.c_void_p]),
+    ("zg16_r1cs_density", C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    ("zg16_prove", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                             u64p, u64p, C.POINTER(Proof)]),
+    ("zg16_prove_partial", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                     C.POINTER(Partial)]),
+    ("zg16_prove_finish", C.c_int, [C.POINTER(PkView), C.POINTER(Partial), C.c_size_t, u64p, u64p,
+                                    C.POINTER(Proof)]),
+    ("zg16_ntt", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint, C.c_int, C.c_int, C.c_int]),
+    ("zg16_h_coefficients", C.c_int, [C.c_void_p, u64p, u64p, u64p, C.c_size_t, u64p, C.POINTER(C.c_size_t)]),
+    ("zg16_msm_g1", C.c_int, [C.c_void_p, u64p, C.c_size_t, u64p, C.c_size_t, u8p, u64p]),
+    ("zg16_msm_g2", C.c_int, [C.c_void_p, u64p, C.c_size_t, u64p, C.c_size_t, u8p, u64p]),
+    ("zg16_spmv", C.c_int, [C.c_void_p, C.c_void_p, u64p, u64p, u64p, u64p, u64p]),
+    ("zg16_last_timings", C.c_int, [C.c_void_p, C.POINTER(Timings)]),
+]
+
+_lib = None
+
+
+def load():
+    """Load the HIP library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "%s is missing: build it with `make -C zinc_amd/csrc` (or __graft_entry__.build()); "
+                "there is no CPU fallback" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+class Groth16Error(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("%s: %s" % (STATUS_NAMES.get(status, status), message))
+        self.status = status
+        self.status_name = STATUS_NAMES.get(status, str(status))
+
+
+def as_u64p(arr):
+    assert arr.dtype == np.uint64 and arr.flags["C_CONTIGUOUS"]
+    return arr.ctypes.data_as(u64p)
+
+
+def as_u32p(arr):
+    assert arr.dtype == np.uint32 and arr.flags["C_CONTIGUOUS"]
+    return arr.ctypes.data_as(u32p)
