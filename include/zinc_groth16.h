@@ -161,6 +161,15 @@ zg16_status zg16_msm_g2(zg16_ctx* ctx, const uint64_t* bases, size_t n_bases,
 zg16_status zg16_spmv(zg16_ctx* ctx, const zg16_r1cs* r1cs, const uint64_t* z_in,
                       const uint64_t* z_aux, uint64_t* a, uint64_t* b, uint64_t* c);
 
+/* ---- key-generation support ------------------------------------------------------------------
+ * out[i] = scalars[i] * base as affine points (scalars are Montgomery Fr, host memory).  This is the
+ * group half of bellman `generate_parameters` (zinc-vm/src/core/circuit/facade.rs:126): every key
+ * point is a known scalar times one generator.  Not used while proving. */
+zg16_status zg16_fixed_base_g1(zg16_ctx* ctx, const uint64_t base[8], const uint64_t* scalars, size_t n,
+                               uint64_t* out);
+zg16_status zg16_fixed_base_g2(zg16_ctx* ctx, const uint64_t base[16], const uint64_t* scalars, size_t n,
+                               uint64_t* out);
+
 /* ---- timing of the last zg16_prove / zg16_prove_partial on this context -------------------- */
 typedef struct {
   float upload_ms, spmv_ms, ntt_ms, msm_g1_ms, msm_g2_ms, finish_ms, total_ms;

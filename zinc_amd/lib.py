@@ -81,6 +81,8 @@ SYMBOLS = [
     ("zg16_msm_g1", C.c_int, [C.c_void_p, u64p, C.c_size_t, u64p, C.c_size_t, u8p, u64p]),
     ("zg16_msm_g2", C.c_int, [C.c_void_p, u64p, C.c_size_t, u64p, C.c_size_t, u8p, u64p]),
     ("zg16_spmv", C.c_int, [C.c_void_p, C.c_void_p, u64p, u64p, u64p, u64p, u64p]),
+    ("zg16_fixed_base_g1", C.c_int, [C.c_void_p, u64p, u64p, C.c_size_t, u64p]),
+    ("zg16_fixed_base_g2", C.c_int, [C.c_void_p, u64p, u64p, C.c_size_t, u64p]),
     ("zg16_last_timings", C.c_int, [C.c_void_p, C.POINTER(Timings)]),
 ]
 
