@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Groth16 prove latency on MI355X: synthetic zinc-shaped R1CS, full prove through the C ABI.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--log-rows 20] [--dense]
+
+One "step" is one complete proof (row evaluation, 7 NTTs, the multiexps, assembly) of the same
+circuit and witness, which are resident in HBM before the timed region starts; the proving key
+and constraint matrices are uploaded once, as a prover service would keep them.  With N > 1
+(launched by torch.distributed.run, one rank per GPU) every rank holds 1/N of each key query,
+computes the partial multiexp sums of its point range, and rank 0 assembles the proof from the
+partials gathered over RCCL; the reported time is the max over ranks ("strong" scaling: the
+proof is the same size whatever N is).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+# ---- algorithmic work per unit (stated in DESIGN.md) ------------------------------------------
+MAD_PER_FQ_MUL = 136               # 8x8 + 8x8 + 8 32-bit multiply-adds in one CIOS product
+FQ_MUL_PER_G1_MADD = 10            # XYZZ mixed addition: 8M + 2S
+FQ_MUL_PER_G2_MADD = 8 * 3 + 2 * 2  # Fq2 mul = 3 Fq mul (Karatsuba), Fq2 sqr = 2
+VALU_MAD_PEAK = 256 * 4 * 16 * 2.4e9  # v_mad_u64_u32: 16 lanes/clk/SIMD x 1024 SIMDs x 2.4 GHz
+HBM_PEAK = 8.0e12
+
+TOXIC = dict(k1=0x1234567, k2=0x7654321, alpha=0xA11CE5, beta=0xBEEF77, gamma=0x6A33A, delta=0xDE17A, tau=0x7A0F00D)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log-rows", type=int, default=20)
+    ap.add_argument("--dense", action="store_true", help="all aux values uniform (multiexp worst case)")
+    ap.add_argument("--cpu-log-rows", type=int, default=16, help="circuit size of the CPU-baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline_leg(ctx, log_rows, dense):
+    """Time the CPU restatement of the bellman prover on a bounded sample of the same workload and
+    check that the GPU produces the identical proof for it.  The only place this file touches oracle/."""
+    from oracle import cpu_binding as cb
+    from zinc_amd import workload
+    from zinc_amd.groth16 import prove_recorded
+    from zinc_amd.fields import ints_to_mont, R_MOD
+    circ = workload.SyntheticCircuit(1 << log_rows, dense=dense)
+    params = workload.generate_parameters(ctx, circ, TOXIC)
+    r1cs = circ.r1cs()
+    zi, za = circ.witness()
+    rs = ints_to_mont([0x1CEB00DA, 0x5EED5EED], R_MOD)
+    threads = min(cb.hardware_threads() or 1, int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or 1 << 30)
+    st, cpu_proof, tm = cb.prove(params, r1cs, zi, za, rs[0], rs[1], threads)
+    assert st == 0, "CPU baseline prover failed with status %d" % st
+    key, mat = params.upload(ctx), r1cs.upload(ctx)
+    gpu = prove_recorded(ctx, key, mat, zi, za, rs[0], rs[1])
+    key.free()
+    mat.free()
+    same = all(np.array_equal(np.frombuffer(bytes(g), dtype=np.uint64), c)
+               for g, c in zip((gpu.raw.a, gpu.raw.b, gpu.raw.c), cpu_proof))
+    return {"value": tm["total_s"], "unit": "s", "cores": threads, "kind": "port",
+            "sample": "full prove of the same synthetic circuit at 2^%d rows (1/%d of the GPU workload), "
+                      "restated bellman algorithms, %d threads; fft %.3fs multiexp %.3fs"
+                      % (log_rows, 1, threads, tm["fft_s"], tm["multiexp_s"]),
+            "log_rows": log_rows, "constraints_per_s": (1 << log_rows) / tm["total_s"],
+            "gpu_proof_identical": bool(same)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+
+    import zinc_amd
+    from zinc_amd import workload, lib as zlib
+    from zinc_amd.fields import ints_to_mont, R_MOD
+    from zinc_amd.groth16 import _check
+
+    ctx = zinc_amd.Context(local_rank)
+    L = ctx._lib
+    n_rows = 1 << args.log_rows
+    t0 = time.time()
+    circ = workload.SyntheticCircuit(n_rows, dense=args.dense)
+    params = workload.generate_parameters(ctx, circ, TOXIC)
+    r1cs = circ.r1cs()
+    key = params.upload(ctx, rank, world)
+    mat = r1cs.upload(ctx)
+    zi, za = circ.witness()
+    z_in_dev = torch.from_numpy(zi.view(np.int64)).cuda()
+    z_aux_dev = torch.from_numpy(za.view(np.int64)).cuda()
+    rs = ints_to_mont([0x1CEB00DA, 0x5EED5EED], R_MOD)
+    r_p, s_p = zlib.as_u64p(rs[0]), zlib.as_u64p(rs[1])
+    setup_s = time.time() - t0
+    pk_view = params.view()
+    dens = mat.density()
+
+    part = zlib.Partial()
+    proof = zlib.Proof()
+    gathered = torch.empty((world, C.sizeof(zlib.Partial)), dtype=torch.uint8, device="cuda") if world > 1 else None
+
+    def step():
+        _check(ctx.handle, L.zg16_prove_partial(ctx.handle, key.handle, mat.handle, C.c_void_p(z_in_dev.data_ptr()),
+                                                C.c_void_p(z_aux_dev.data_ptr()), 1, C.byref(part)))
+        if world == 1:
+            parts, n = C.byref(part), 1
+        else:
+            mine = torch.frombuffer(bytearray(bytes(part)), dtype=torch.uint8).cuda()
+            dist.all_gather_into_tensor(gathered.view(-1), mine)
+            if rank != 0:
+                return
+            host = gathered.cpu().numpy().tobytes()
+            arr = (zlib.Partial * world).from_buffer_copy(host)
+            parts, n = arr, world
+        st = L.zg16_prove_finish(C.byref(pk_view), parts, n, r_p, s_p, C.byref(proof))
+        assert st == 0, "zg16_prove_finish failed: %d" % st
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.profile(True, reset=True)
+    fence()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t_start
+    stats = ctx.kernel_stats()
+    stage = ctx.timings()
+    ctx.profile(False, reset=False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        # dominant kernel by accumulated device time on this rank
+        dom = max(stats.items(), key=lambda kv: kv[1][0])
+        per_kernel = {k: {"ms_per_step": v[0] / args.steps, "launches_per_step": v[1] / args.steps}
+                      for k, v in stats.items() if v[1]}
+
+        def valu_roofline(name, fq_mul_per_add):
+            ms, launches, adds = stats[name]
+            if not launches:
+                return None
+            ach = adds * fq_mul_per_add * MAD_PER_FQ_MUL / (ms * 1e-3)
+            return {"kernel": name, "bound": "valu", "achieved": ach / 1e12, "peak": VALU_MAD_PEAK / 1e12,
+                    "unit": "Tmad/s", "frac": ach / VALU_MAD_PEAK, "traffic": None,
+                    "avg_launch_ms": ms / launches, "adds_per_launch": adds / launches}
+
+        def hbm_roofline(name):
+            ms, launches, nbytes = stats[name]
+            if not launches:
+                return None
+            ach = nbytes / (ms * 1e-3)
+            return {"kernel": name, "bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK, "traffic": None, "avg_launch_ms": ms / launches,
+                    "bytes_per_launch": nbytes / launches}
+
+        rooflines = {
+            "k_accumulate<G1,level0>": valu_roofline("k_accumulate<G1,level0>", FQ_MUL_PER_G1_MADD),
+            "k_accumulate<G2,level0>": valu_roofline("k_accumulate<G2,level0>", FQ_MUL_PER_G2_MADD),
+            "k_ntt_pass": hbm_roofline("k_ntt_pass"),
+            "k_spmv_short+long": hbm_roofline("k_spmv_short+long"),
+        }
+        roofline = rooflines.get(dom[0]) or rooflines["k_accumulate<G1,level0>"]
+        out = {
+            "metric": "groth16_prove_latency_2^%d_constraints" % args.log_rows,
+            "value": ms_per_step / 1e3,
+            "unit": "s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": False,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "u32x8 Montgomery (BN254 Fr/Fq, integer)",
+            "data": "synthetic",
+            "config": {"workload": "synthetic zinc-shaped R1CS, 2^%d rows (%s witness), full Groth16 prove incl. G2 multiexp"
+                                   % (args.log_rows, "dense" if args.dense else "80% bit"),
+                       "n_inputs": circ.n_inputs, "n_aux": circ.n_aux, "nnz": [int(m[1].shape[0]) for m in r1cs.mats],
+                       "a_aux_density": dens[0], "b_aux_density": dens[2], "parallelism": "msm-point-range x%d" % world},
+            "constraints_per_s": n_rows / (ms_per_step / 1e3),
+            "stage_ms_last_step": stage,
+            "kernels": per_kernel,
+            "roofline": roofline,
+            "roofline_other": {k: v for k, v in rooflines.items() if v and v is not roofline},
+            "setup_s_untimed": setup_s,
+        }
+        g1 = stats["k_accumulate<G1,level0>"]
+        if g1[0]:
+            out["msm_g1_accumulate_points_per_s"] = g1[2] / (g1[0] * 1e-3)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_leg(ctx, args.cpu_log_rows, args.dense)
+            out["cpu_baseline"]["sample"] = out["cpu_baseline"]["sample"].replace(
+                "(1/1 of", "(1/%d of" % (1 << (args.log_rows - args.cpu_log_rows)))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

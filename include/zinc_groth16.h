@@ -176,6 +176,17 @@ typedef struct {
 } zg16_timings;
 zg16_status zg16_last_timings(const zg16_ctx* ctx, zg16_timings* out);
 
+/* ---- per-kernel timing -------------------------------------------------------------------------
+ * With profiling enabled every kernel launch is bracketed by two HIP events on the context's
+ * stream; totals accumulate per kernel kind until reset.  `units` is the algorithmic work the
+ * launches covered: bytes for the SpMV / NTT kernels, terms for k_digits, additions for the
+ * k_accumulate kernels, buckets for k_scan / k_bucket_reduce. */
+zg16_status zg16_profile_enable(zg16_ctx* ctx, int on);
+zg16_status zg16_profile_reset(zg16_ctx* ctx);
+int         zg16_profile_kernel_count(void);
+zg16_status zg16_profile_get(const zg16_ctx* ctx, int kernel, const char** name, double* total_ms,
+                             uint64_t* launches, double* units);
+
 #ifdef __cplusplus
 }
 #endif

@@ -342,6 +342,7 @@ zg16_status zg16_prove_partial(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1cs
   ZG_HIP(ctx, hipEventRecord(e_end, ctx->stream));
   ZG_HIP(ctx, hipEventSynchronize(e_end));
   ZG_HIP(ctx, hipEventElapsedTime(&tm.total_ms, e_begin, e_end));
+  profile_collect(ctx);
   return ZG16_OK;
 }
 
@@ -414,6 +415,35 @@ zg16_status zg16_prove(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1cs* r, con
   ctx->timings.finish_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   ctx->timings.total_ms += ctx->timings.finish_ms;
   if (st != ZG16_OK) return fail(ctx, st, "final assembly failed");
+  return ZG16_OK;
+}
+
+static const char* const kKernelNames[K_COUNT] = {
+    "k_spmv_short+long", "k_ntt_pass", "k_scale_powers", "k_mul_sub_scale", "k_digits", "k_scan",
+    "k_accumulate<G1,level0>", "k_accumulate<G2,level0>", "k_accumulate<G1,level>=1>", "k_accumulate<G2,level>=1>",
+    "k_bucket_reduce<G1>", "k_bucket_reduce<G2>"};
+
+zg16_status zg16_profile_enable(zg16_ctx* ctx, int on) {
+  if (!ctx) return ZG16_ERR_INVALID_ARGUMENT;
+  ctx->profile = on != 0;
+  return ZG16_OK;
+}
+
+zg16_status zg16_profile_reset(zg16_ctx* ctx) {
+  if (!ctx) return ZG16_ERR_INVALID_ARGUMENT;
+  for (auto& k : ctx->kstat) k = KernelStat();
+  return ZG16_OK;
+}
+
+int zg16_profile_kernel_count(void) { return K_COUNT; }
+
+zg16_status zg16_profile_get(const zg16_ctx* ctx, int kernel, const char** name, double* total_ms, uint64_t* launches,
+                             double* units) {
+  if (!ctx || kernel < 0 || kernel >= K_COUNT) return ZG16_ERR_INVALID_ARGUMENT;
+  if (name) *name = kKernelNames[kernel];
+  if (total_ms) *total_ms = ctx->kstat[kernel].ms;
+  if (launches) *launches = ctx->kstat[kernel].launches;
+  if (units) *units = ctx->kstat[kernel].units;
   return ZG16_OK;
 }
 

@@ -18,8 +18,29 @@ struct MsmScratch;  // msm.hip
 
 }  // namespace zg
 
+namespace zg {
+// Kernels that per-launch timing (zg16_profile_*) distinguishes.
+enum KernelId {
+  K_SPMV = 0, K_NTT_PASS, K_NTT_SCALE, K_NTT_POINTWISE, K_MSM_DIGITS, K_MSM_SCAN, K_MSM_ACC0_G1, K_MSM_ACC0_G2,
+  K_MSM_ACCN_G1, K_MSM_ACCN_G2, K_MSM_REDUCE_G1, K_MSM_REDUCE_G2, K_COUNT
+};
+struct KernelStat {
+  double ms = 0, units = 0;
+  uint64_t launches = 0;
+};
+struct PendingTiming {
+  int id;
+  double units;
+  hipEvent_t a, b;
+};
+}  // namespace zg
+
 struct zg16_ctx {
   int device = 0;
+  bool profile = false;
+  zg::KernelStat kstat[zg::K_COUNT];
+  std::vector<zg::PendingTiming> pending;
+  std::vector<hipEvent_t> event_pool;
   hipStream_t stream = nullptr;      // stream all kernels are issued on
   hipStream_t own_stream = nullptr;  // created by the context
   hipStream_t aux_stream = nullptr;  // second stream for overlapping independent stages
@@ -74,6 +95,53 @@ inline zg16_status scratch_get(zg16_ctx* ctx, int slot, size_t bytes, void** out
   }
   *out = ctx->scratch[slot];
   return ZG16_OK;
+}
+
+// Brackets the launches issued during its lifetime with two events on the context's stream when
+// profiling is on; zg::profile_collect turns the pairs into per-kernel totals after a sync.
+struct KernelTimer {
+  zg16_ctx* ctx;
+  PendingTiming p;
+  bool on;
+  KernelTimer(zg16_ctx* c, int id, double units) : ctx(c), on(c->profile) {
+    if (!on) return;
+    p.id = id;
+    p.units = units;
+    p.a = grab();
+    p.b = grab();
+    if (!p.a || !p.b) { on = false; return; }
+    (void)hipEventRecord(p.a, ctx->stream);
+  }
+  ~KernelTimer() {
+    if (!on) return;
+    (void)hipEventRecord(p.b, ctx->stream);
+    ctx->pending.push_back(p);
+  }
+  hipEvent_t grab() {
+    if (!ctx->event_pool.empty()) {
+      hipEvent_t e = ctx->event_pool.back();
+      ctx->event_pool.pop_back();
+      return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+  }
+};
+
+// Call with the stream idle (after a synchronize).
+inline void profile_collect(zg16_ctx* ctx) {
+  for (auto& p : ctx->pending) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+      ctx->kstat[p.id].ms += ms;
+      ctx->kstat[p.id].units += p.units;
+      ctx->kstat[p.id].launches++;
+    }
+    ctx->event_pool.push_back(p.a);
+    ctx->event_pool.push_back(p.b);
+  }
+  ctx->pending.clear();
 }
 
 static inline unsigned ceil_log2(size_t n) {

@@ -138,15 +138,46 @@ __global__ __launch_bounds__(256) void k_digits(JobTable<F> jt, MsmShape sh, uin
   }
 }
 
-// Exclusive scan of hist[0..count) into off[0..count] and cursor[0..count); one workgroup.
-__global__ __launch_bounds__(1024) void k_scan(const uint32_t* __restrict__ hist, uint32_t count,
-                                               uint32_t* __restrict__ off, uint32_t* __restrict__ cursor) {
+// Exclusive scan of hist[0..count) into off[0..count] (and a copy in cursor[0..count)) in three
+// launches: per-workgroup scans of 4096 counters, a scan of the workgroup totals, a fix-up.
+static constexpr uint32_t SCAN_TILE = 4096;
+
+__global__ __launch_bounds__(256) void k_scan_local(const uint32_t* __restrict__ hist, uint32_t count,
+                                                    uint32_t* __restrict__ off, uint32_t* __restrict__ tile_sum) {
+  __shared__ uint32_t part[256];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t base = blockIdx.x * SCAN_TILE + tid * 16;
+  uint32_t v[16], s = 0;
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    v[i] = base + i < count ? hist[base + i] : 0;
+    s += v[i];
+  }
+  part[tid] = s;
+  __syncthreads();
+  for (uint32_t d = 1; d < 256; d <<= 1) {
+    uint32_t x = tid >= d ? part[tid - d] : 0;
+    __syncthreads();
+    part[tid] += x;
+    __syncthreads();
+  }
+  uint32_t run = tid ? part[tid - 1] : 0;
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    if (base + i < count) off[base + i] = run;
+    run += v[i];
+  }
+  if (tid == 255) tile_sum[blockIdx.x] = part[255];
+}
+
+// One workgroup: exclusive scan of tile_sum[0..ntiles) in place; tile_sum[ntiles] = grand total.
+__global__ __launch_bounds__(1024) void k_scan_tiles(uint32_t* __restrict__ tile_sum, uint32_t ntiles) {
   __shared__ uint32_t part[1024];
   const uint32_t tid = threadIdx.x;
-  const uint32_t per = (count + 1023) / 1024;
-  const uint32_t lo = tid * per, hi = (lo + per < count) ? lo + per : count;
+  const uint32_t per = (ntiles + 1023) / 1024;
+  const uint32_t lo = tid * per, hi = (lo + per < ntiles) ? lo + per : ntiles;
   uint32_t s = 0;
-  for (uint32_t i = lo; i < hi; i++) s += hist[i];
+  for (uint32_t i = lo; i < hi; i++) s += tile_sum[i];
   part[tid] = s;
   __syncthreads();
   for (uint32_t d = 1; d < 1024; d <<= 1) {
@@ -157,11 +188,24 @@ __global__ __launch_bounds__(1024) void k_scan(const uint32_t* __restrict__ hist
   }
   uint32_t run = tid ? part[tid - 1] : 0;
   for (uint32_t i = lo; i < hi; i++) {
-    off[i] = run;
-    cursor[i] = run;
-    run += hist[i];
+    const uint32_t v = tile_sum[i];
+    tile_sum[i] = run;
+    run += v;
   }
-  if (tid == 1023) off[count] = part[1023];
+  if (tid == 1023) tile_sum[ntiles] = part[1023];
+}
+
+__global__ __launch_bounds__(256) void k_scan_fixup(uint32_t* __restrict__ off, uint32_t* __restrict__ cursor,
+                                                    uint32_t count, const uint32_t* __restrict__ tile_sum,
+                                                    uint32_t ntiles) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) {
+    const uint32_t v = off[i] + tile_sum[i / SCAN_TILE];
+    off[i] = v;
+    cursor[i] = v;
+  } else if (i == count) {
+    off[count] = tile_sum[ntiles];
+  }
 }
 
 // Slot range that bucket [s, e) of level 0 occupies at `level`.
@@ -245,33 +289,74 @@ ZG_D XYZZ<F> mul_small(const XYZZ<F>& p, uint32_t k) {
   return acc;
 }
 
-// Window sums: out[w] = sum_b (b+1) * S[w*B + b].  One workgroup per window; lane t folds
-// RED_SEG consecutive buckets by running sums, then the workgroup tree-adds through LDS.
+// Workgroup tree sum through LDS; the result is valid in thread 0.
 template <class F>
-__global__ __launch_bounds__(256) void k_bucket_reduce(const XYZZ<F>* __restrict__ bucket_sum, uint32_t B,
-                                                       XYZZ<F>* __restrict__ out) {
-  __shared__ XYZZ<F> sh[128];
-  const uint32_t w = blockIdx.x, tid = threadIdx.x;
-  const XYZZ<F>* S = bucket_sum + (size_t)w * B;
-  XYZZ<F> total = XYZZ<F>::inf();
-  for (uint32_t seg = tid * RED_SEG; seg < B; seg += 256 * RED_SEG) {
-    const uint32_t hi = seg + RED_SEG < B ? seg + RED_SEG : B;
-    XYZZ<F> run = XYZZ<F>::inf(), acc = XYZZ<F>::inf();
-    for (uint32_t b = hi; b-- > seg;) {
-      add_full(run, S[b]);
-      add_full(acc, run);
-    }
-    // acc = sum (b - seg + 1) S_b ; add seg * run
-    if (seg) add_full(acc, mul_small(run, seg));
-    add_full(total, acc);
-  }
+ZG_D void block_sum(XYZZ<F>& total, XYZZ<F>* sh /* [128] */) {
+  const uint32_t tid = threadIdx.x;
   for (uint32_t stride = 128; stride >= 1; stride >>= 1) {
     if (tid >= stride && tid < 2 * stride) sh[tid - stride] = total;
     __syncthreads();
     if (tid < stride) add_full(total, sh[tid]);
     __syncthreads();
   }
-  if (tid == 0) out[w] = total;
+}
+
+// Window sums, stage 1: part[w][blk] = sum over this workgroup's buckets of (b+1) * S[w*B + b].
+// Grid (blocks per window, W).  A lane folds RED_SEG consecutive buckets by running sums and adds
+// seg_start * (segment sum); the workgroup then tree-adds through LDS.
+template <class F>
+__global__ __launch_bounds__(256) void k_bucket_reduce(const XYZZ<F>* __restrict__ bucket_sum, uint32_t B,
+                                                       XYZZ<F>* __restrict__ part) {
+  __shared__ XYZZ<F> sh[128];
+  const uint32_t w = blockIdx.y, tid = threadIdx.x;
+  const XYZZ<F>* S = bucket_sum + (size_t)w * B;
+  const uint32_t seg = (blockIdx.x * 256 + tid) * RED_SEG;
+  XYZZ<F> acc = XYZZ<F>::inf();
+  if (seg < B) {
+    const uint32_t hi = seg + RED_SEG < B ? seg + RED_SEG : B;
+    XYZZ<F> run = XYZZ<F>::inf();
+    for (uint32_t b = hi; b-- > seg;) {
+      add_full(run, S[b]);
+      add_full(acc, run);
+    }
+    // acc = sum (b - seg + 1) S_b ; add seg * run
+    if (seg) add_full(acc, mul_small(run, seg));
+  }
+  block_sum(acc, sh);
+  if (tid == 0) part[(size_t)w * gridDim.x + blockIdx.x] = acc;
+}
+
+// out[w] = sum of part[w][0..count).  One workgroup per w.
+template <class F>
+__global__ __launch_bounds__(256) void k_sum_partials(const XYZZ<F>* __restrict__ part, uint32_t count,
+                                                      XYZZ<F>* __restrict__ out) {
+  __shared__ XYZZ<F> sh[128];
+  const uint32_t w = blockIdx.x, tid = threadIdx.x;
+  XYZZ<F> acc = XYZZ<F>::inf();
+  for (uint32_t i = tid; i < count; i += 256) add_full(acc, part[(size_t)w * count + i]);
+  block_sum(acc, sh);
+  if (tid == 0) out[w] = acc;
+}
+
+// Plain sum of the bases named by ent[lo..hi) (the scalars equal to one): each lane adds a
+// contiguous share, the workgroup tree-adds, one partial per workgroup.
+template <class F>
+__global__ __launch_bounds__(256) void k_sum_range(JobTable<F> jt, const uint32_t* __restrict__ ent, uint32_t lo,
+                                                   uint32_t hi, XYZZ<F>* __restrict__ part,
+                                                   uint32_t* __restrict__ err_flag) {
+  __shared__ XYZZ<F> sh[128];
+  const uint32_t nthreads = gridDim.x * 256, t = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t per = (hi - lo + nthreads - 1) / nthreads;
+  const uint32_t a = lo + t * per < hi ? lo + t * per : hi;
+  const uint32_t b = a + per < hi ? a + per : hi;
+  XYZZ<F> acc = XYZZ<F>::inf();
+  for (uint32_t i = a; i < b; i++) {
+    const Affine<F> p = load_base(jt, ent[i] & 0x7fffffffu);
+    if (p.is_inf()) *err_flag = 1;
+    add_mixed(acc, p);
+  }
+  block_sum(acc, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = acc;
 }
 
 static uint32_t pick_window(size_t n) {
@@ -346,6 +431,11 @@ static zg16_status msm_run(zg16_ctx* ctx, int scratch_slot, const MsmJob<F>* job
   }
   const size_t o_bsum = o;   o += align((size_t)(sh.nb + 1) * sizeof(XYZZ<F>));
   const size_t o_wsum = o;   o += align((size_t)(sh.W + 1) * sizeof(XYZZ<F>));
+  const uint32_t ntiles = (sh.nb + 1 + SCAN_TILE - 1) / SCAN_TILE;
+  const uint32_t red_blocks = (sh.B + 256 * RED_SEG - 1) / (256 * RED_SEG);
+  const uint32_t max_ones_blocks = 1024;
+  const size_t o_tiles = o;  o += align((size_t)(ntiles + 1) * 4);
+  const size_t o_part = o;   o += align((size_t)(sh.W * red_blocks + max_ones_blocks) * sizeof(XYZZ<F>));
   char* base;
   ZG_TRY(scratch_get(ctx, scratch_slot, o, (void**)&base));
   uint32_t* hist = (uint32_t*)(base + o_hist);
@@ -356,22 +446,49 @@ static zg16_status msm_run(zg16_ctx* ctx, int scratch_slot, const MsmJob<F>* job
   uint32_t* key0 = (uint32_t*)(base + o_key0);
   XYZZ<F>* bsum = (XYZZ<F>*)(base + o_bsum);
   XYZZ<F>* wsum = (XYZZ<F>*)(base + o_wsum);
+  uint32_t* tiles = (uint32_t*)(base + o_tiles);
+  XYZZ<F>* part = (XYZZ<F>*)(base + o_part);
   hipStream_t st = ctx->stream;
 
   ZG_HIP(ctx, hipMemsetAsync(base, 0, o_ent, st));  // hist, off, cursor, err
   ZG_HIP(ctx, hipMemsetAsync(bsum, 0, (size_t)(sh.nb + 1) * sizeof(XYZZ<F>), st));
   const unsigned dgrid = (unsigned)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256);
-  k_digits<F, false><<<dgrid, 256, 0, st>>>(jt, sh, hist, cursor, ent, key0);
-  k_scan<<<1, 1024, 0, st>>>(hist, sh.nb + 1, off, cursor);
-  k_digits<F, true><<<dgrid, 256, 0, st>>>(jt, sh, hist, cursor, ent, key0);
-  uint32_t entries = 0;
-  ZG_HIP(ctx, hipMemcpyAsync(&entries, off + sh.nb + 1, 4, hipMemcpyDeviceToHost, st));
+  constexpr bool is_g2 = sizeof(F) > sizeof(Fq);
+  {
+    KernelTimer kt(ctx, K_MSM_DIGITS, (double)n);
+    k_digits<F, false><<<dgrid, 256, 0, st>>>(jt, sh, hist, cursor, ent, key0);
+  }
+  {
+    KernelTimer kt(ctx, K_MSM_SCAN, (double)sh.nb);
+    k_scan_local<<<ntiles, 256, 0, st>>>(hist, sh.nb + 1, off, tiles);
+    k_scan_tiles<<<1, 1024, 0, st>>>(tiles, ntiles);
+    k_scan_fixup<<<(sh.nb + 2 + 255) / 256, 256, 0, st>>>(off, cursor, sh.nb + 1, tiles, ntiles);
+  }
+  {
+    KernelTimer kt(ctx, K_MSM_DIGITS, (double)n);
+    k_digits<F, true><<<dgrid, 256, 0, st>>>(jt, sh, hist, cursor, ent, key0);
+  }
+  uint32_t tail[2] = {0, 0};  // start of the ones range, total entries
+  ZG_HIP(ctx, hipMemcpyAsync(tail, off + sh.nb, 8, hipMemcpyDeviceToHost, st));
   ZG_HIP(ctx, hipStreamSynchronize(st));
-  // levels, sized by the actual entry count
-  size_t slots = entries;
+  // the scalars equal to one: a plain tree sum, kept out of the segmented reduction
+  const uint32_t n_ones = tail[1] - tail[0];
+  if (n_ones) {
+    uint32_t g = (n_ones + 256 * 16 - 1) / (256 * 16);
+    if (g > max_ones_blocks) g = max_ones_blocks;
+    KernelTimer kt(ctx, is_g2 ? K_MSM_ACC0_G2 : K_MSM_ACC0_G1, (double)n_ones);
+    k_sum_range<F><<<g, 256, 0, st>>>(jt, ent, tail[0], tail[1], part + (size_t)sh.W * red_blocks, err);
+    k_sum_partials<F><<<1, 256, 0, st>>>(part + (size_t)sh.W * red_blocks, g, wsum + sh.W);
+  } else {
+    ZG_HIP(ctx, hipMemsetAsync(wsum + sh.W, 0, sizeof(XYZZ<F>), st));
+  }
+  // levels, sized by the actual entry count of the digit buckets
+  size_t slots = tail[0];
   for (int l = 0; slots > 0; l++) {
     const size_t chunks = (slots + ACC_K - 1) / ACC_K;
     const unsigned grid = (unsigned)((chunks + 255) / 256);
+    KernelTimer kt(ctx, l == 0 ? (is_g2 ? K_MSM_ACC0_G2 : K_MSM_ACC0_G1) : (is_g2 ? K_MSM_ACCN_G2 : K_MSM_ACCN_G1),
+                   (double)slots);
     if (l == 0)
       k_accumulate<F, true><<<grid, 256, 0, st>>>(jt, 0, (uint32_t)slots, key0, ent, nullptr, off,
                                                   (uint32_t*)(base + o_keys[1]), (XYZZ<F>*)(base + o_pts[1]), bsum, err);
@@ -382,12 +499,15 @@ static zg16_status msm_run(zg16_ctx* ctx, int scratch_slot, const MsmJob<F>* job
     if (chunks <= 1) break;
     slots = 2 * chunks;
   }
-  k_bucket_reduce<F><<<sh.W, 256, 0, st>>>(bsum, sh.B, wsum);
+  {
+    KernelTimer kt(ctx, is_g2 ? K_MSM_REDUCE_G2 : K_MSM_REDUCE_G1, (double)sh.nb);
+    k_bucket_reduce<F><<<dim3(red_blocks, sh.W), 256, 0, st>>>(bsum, sh.B, part);
+    k_sum_partials<F><<<sh.W, 256, 0, st>>>(part, red_blocks, wsum);
+  }
   ZG_HIP(ctx, hipGetLastError());
   std::vector<XYZZ<F>> hw(sh.W + 1);
   uint32_t herr = 0;
-  ZG_HIP(ctx, hipMemcpyAsync(hw.data(), wsum, sh.W * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
-  ZG_HIP(ctx, hipMemcpyAsync(&hw[sh.W], bsum + sh.nb, sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
+  ZG_HIP(ctx, hipMemcpyAsync(hw.data(), wsum, (sh.W + 1) * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
   ZG_HIP(ctx, hipMemcpyAsync(&herr, err, 4, hipMemcpyDeviceToHost, st));
   ZG_HIP(ctx, hipStreamSynchronize(st));
   if (herr) return fail(ctx, ZG16_ERR_UNEXPECTED_IDENTITY, "multiexp consumed a base at infinity");

@@ -257,6 +257,7 @@ static zg16_status ntt_raw(zg16_ctx* ctx, NttDomain* d, const Fr* src, Fr* dst, 
     p.in_lo = p.out_lo = p.tw_lo_mul = 1u << p.logT;
     p.tw_scale = 1;
     const uint32_t grid = (R2 * R3) >> p.logT;
+    KernelTimer kt(ctx, K_NTT_PASS, 64.0 * (double)((size_t)1 << n));
     k_ntt_pass<<<grid, 256, 0, st>>>(src, tmp, p, d->w_small[dir], d->w_lo[dir], d->w_hi[dir]);
   }
   if (r2) {  // pass B: over i2, tile of adjacent i3, one k1 per block row
@@ -270,6 +271,7 @@ static zg16_status ntt_raw(zg16_ctx* ctx, NttDomain* d, const Fr* src, Fr* dst, 
     p.in_lo = p.out_lo = p.tw_lo_mul = 1u << p.logT;
     p.tw_scale = R1;
     const uint32_t grid = R1 * (R3 >> p.logT);
+    KernelTimer kt(ctx, K_NTT_PASS, 64.0 * (double)((size_t)1 << n));
     k_ntt_pass<<<grid, 256, 0, st>>>(tmp, tmp, p, d->w_small[dir], d->w_lo[dir], d->w_hi[dir]);
   }
   {  // pass C: over i3 (contiguous), tile of adjacent k1, scatter to natural order
@@ -288,6 +290,7 @@ static zg16_status ntt_raw(zg16_ctx* ctx, NttDomain* d, const Fr* src, Fr* dst, 
     p.tw_scale = 0;
     p.load_j_fast = 1;
     const uint32_t grid = (R1 >> p.logT) * R2;
+    KernelTimer kt(ctx, K_NTT_PASS, 64.0 * (double)((size_t)1 << n));
     k_ntt_pass<<<grid, 256, 0, st>>>(r1 ? tmp : src, dst, p, d->w_small[dir], d->w_lo[dir], d->w_hi[dir]);
   }
   ZG_HIP(ctx, hipGetLastError());
@@ -327,12 +330,21 @@ zg16_status h_pipeline_device(zg16_ctx* ctx, Fr* a, Fr* b, Fr* c, unsigned log_m
   for (Fr* p : polys) {
     // ifft, then coset_fft; the 1/m of the ifft rides on the coset pre-scaling table
     ZG_TRY(ntt_raw(ctx, d, p, p, true));
-    k_scale_powers<<<ew_grid(m), 256, 0, st>>>(p, m, d->gm_lo, d->g_hi);
+    {
+      KernelTimer kt(ctx, K_NTT_SCALE, 64.0 * m);
+      k_scale_powers<<<ew_grid(m), 256, 0, st>>>(p, m, d->gm_lo, d->g_hi);
+    }
     ZG_TRY(ntt_raw(ctx, d, p, p, false));
   }
-  k_mul_sub_scale<<<ew_grid(m), 256, 0, st>>>(a, b, c, m, d->zinv);
+  {
+    KernelTimer kt(ctx, K_NTT_POINTWISE, 128.0 * m);
+    k_mul_sub_scale<<<ew_grid(m), 256, 0, st>>>(a, b, c, m, d->zinv);
+  }
   ZG_TRY(ntt_raw(ctx, d, a, a, true));
-  k_scale_powers<<<ew_grid(m), 256, 0, st>>>(a, m, d->ginvm_lo, d->ginv_hi);
+  {
+    KernelTimer kt(ctx, K_NTT_SCALE, 64.0 * m);
+    k_scale_powers<<<ew_grid(m), 256, 0, st>>>(a, m, d->ginvm_lo, d->ginv_hi);
+  }
   ZG_HIP(ctx, hipGetLastError());
   return ZG16_OK;
 }

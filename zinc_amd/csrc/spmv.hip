@@ -60,6 +60,7 @@ zg16_status spmv_device(zg16_ctx* ctx, const zg16_r1cs* r, const Fr* z, Fr* a, F
   hipStream_t st = ctx->stream;
   for (int k = 0; k < 3; k++) {
     const R1csMatrix& m = r->m[k];
+    KernelTimer kt(ctx, K_SPMV, (double)m.nnz * 36 + (double)(r->n_in + r->n_aux) * 32 + (double)r->n_rows * 36);
     if (r->n_rows)
       k_spmv_short<<<(unsigned)((r->n_rows + 255) / 256), 256, 0, st>>>(m.row_ptr, m.col, m.coeff, z, outs[k],
                                                                         (uint32_t)r->n_rows);

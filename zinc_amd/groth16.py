@@ -59,6 +59,21 @@ class Context:
         _check(self.handle, self._lib.zg16_last_timings(self.handle, C.byref(t)))
         return {n: getattr(t, n) for n, _ in t._fields_}
 
+    def profile(self, on=True, reset=True):
+        _check(self.handle, self._lib.zg16_profile_enable(self.handle, int(on)))
+        if reset:
+            _check(self.handle, self._lib.zg16_profile_reset(self.handle))
+
+    def kernel_stats(self):
+        """{kernel name: (total_ms, launches, units)} since the last reset."""
+        out = {}
+        for k in range(self._lib.zg16_profile_kernel_count()):
+            name, ms, n, units = C.c_char_p(), C.c_double(), C.c_uint64(), C.c_double()
+            _check(self.handle, self._lib.zg16_profile_get(self.handle, k, C.byref(name), C.byref(ms), C.byref(n),
+                                                           C.byref(units)))
+            out[name.value.decode()] = (ms.value, n.value, units.value)
+        return out
+
     # ---- stand-alone stages -------------------------------------------------------------
     def ntt(self, data, inverse=False, coset=False):
         """data: (2^k, 4) uint64 Montgomery Fr; returns the transformed copy."""

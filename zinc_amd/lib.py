@@ -83,6 +83,11 @@ SYMBOLS = [
     ("zg16_spmv", C.c_int, [C.c_void_p, C.c_void_p, u64p, u64p, u64p, u64p, u64p]),
     ("zg16_fixed_base_g1", C.c_int, [C.c_void_p, u64p, u64p, C.c_size_t, u64p]),
     ("zg16_fixed_base_g2", C.c_int, [C.c_void_p, u64p, u64p, C.c_size_t, u64p]),
+    ("zg16_profile_enable", C.c_int, [C.c_void_p, C.c_int]),
+    ("zg16_profile_reset", C.c_int, [C.c_void_p]),
+    ("zg16_profile_kernel_count", C.c_int, []),
+    ("zg16_profile_get", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double),
+                                   C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
     ("zg16_last_timings", C.c_int, [C.c_void_p, C.POINTER(Timings)]),
 ]
 
