@@ -105,30 +105,16 @@ def main():
     z_in_dev = torch.from_numpy(zi.view(np.int64)).cuda()
     z_aux_dev = torch.from_numpy(za.view(np.int64)).cuda()
     rs = ints_to_mont([0x1CEB00DA, 0x5EED5EED], R_MOD)
-    r_p, s_p = zlib.as_u64p(rs[0]), zlib.as_u64p(rs[1])
     setup_s = time.time() - t0
     pk_view = params.view()
     dens = mat.density()
 
-    part = zlib.Partial()
-    proof = zlib.Proof()
-    gathered = torch.empty((world, C.sizeof(zlib.Partial)), dtype=torch.uint8, device="cuda") if world > 1 else None
+    from zinc_amd.distributed import prove_sharded
+    dev = torch.device("cuda", local_rank) if world > 1 else None
 
     def step():
-        _check(ctx.handle, L.zg16_prove_partial(ctx.handle, key.handle, mat.handle, C.c_void_p(z_in_dev.data_ptr()),
-                                                C.c_void_p(z_aux_dev.data_ptr()), 1, C.byref(part)))
-        if world == 1:
-            parts, n = C.byref(part), 1
-        else:
-            mine = torch.frombuffer(bytearray(bytes(part)), dtype=torch.uint8).cuda()
-            dist.all_gather_into_tensor(gathered.view(-1), mine)
-            if rank != 0:
-                return
-            host = gathered.cpu().numpy().tobytes()
-            arr = (zlib.Partial * world).from_buffer_copy(host)
-            parts, n = arr, world
-        st = L.zg16_prove_finish(C.byref(pk_view), parts, n, r_p, s_p, C.byref(proof))
-        assert st == 0, "zg16_prove_finish failed: %d" % st
+        return prove_sharded(ctx, key, mat, z_in_dev.data_ptr(), z_aux_dev.data_ptr(), 1, pk_view, rs[0], rs[1],
+                             rank, world, dev)
 
     def fence():
         if world > 1:

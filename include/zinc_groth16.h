@@ -176,6 +176,17 @@ typedef struct {
 } zg16_timings;
 zg16_status zg16_last_timings(const zg16_ctx* ctx, zg16_timings* out);
 
+/* ---- primitive self-test hooks -----------------------------------------------------------------
+ * Element-wise evaluation of the device field / group primitives so tests can pin them against
+ * golden vectors (pairing_ce / ff_ce semantics; those crates are not part of the reference tree).
+ * field: 0 Fr, 1 Fq, 2 Fq2.  op: 0 add, 1 sub, 2 mul, 3 square, 4 negate, 5 inverse (0 -> 0).
+ * group: 1 G1, 2 G2.  op: 0 double p, 1 p + q (mixed), 2 p + q (projective), 3 k * p with k a
+ * Montgomery Fr.  Inputs and outputs are affine points / Montgomery limbs in host memory. */
+zg16_status zg16_selftest_field(zg16_ctx* ctx, int field, int op, const uint64_t* a, const uint64_t* b,
+                                size_t n, uint64_t* out);
+zg16_status zg16_selftest_group(zg16_ctx* ctx, int group, int op, const uint64_t* p, const uint64_t* q,
+                                size_t n, uint64_t* out);
+
 /* ---- per-kernel timing -------------------------------------------------------------------------
  * With profiling enabled every kernel launch is bracketed by two HIP events on the context's
  * stream; totals accumulate per kernel kind until reset.  `units` is the algorithmic work the

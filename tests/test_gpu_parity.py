@@ -1,0 +1,363 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against golden vectors, the oracles on
+seeded inputs, and size-independent properties at the benchmark's full sizes.  Bar: bit-exact
+(all arithmetic is integer / modular; there is no floating point on this path)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import golden, unhex, FixtureCircuit, FixtureKey, fixture_proof
+from zinc_amd import lib as zlib
+from zinc_amd.fields import (R_MOD, Q_MOD, ints_to_mont, mont_to_ints, g1_to_mont, g2_to_mont, mont_to_g1, mont_to_g2)
+from zinc_amd.groth16 import (ProvingAssignment, Parameters, SynthesisError, create_proof, prove_recorded, R1CS)
+
+pytestmark = pytest.mark.gpu
+
+
+def rand_fr(rng, n):
+    """n canonical field elements as Montgomery limbs (top limb below 2^61 < the modulus' top limb)."""
+    x = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(n, 4), dtype=np.uint64)
+    x[:, 3] >>= np.uint64(3)
+    return x
+
+
+# ------------------------------------------------------------------------------ primitives
+def _field(ctx, field, op, a, b):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    b = np.ascontiguousarray(b, dtype=np.uint64)
+    out = np.zeros_like(a)
+    n = a.shape[0]
+    st = ctx._lib.zg16_selftest_field(ctx.handle, field, op, zlib.as_u64p(a), zlib.as_u64p(b), n, zlib.as_u64p(out))
+    assert st == 0, ctx._lib.zg16_last_error(ctx.handle)
+    return out
+
+
+@pytest.mark.parametrize("name,field,mod", [("fr_ops", 0, R_MOD), ("fq_ops", 1, Q_MOD)])
+def test_field_ops_golden(gpu_ctx, name, field, mod):
+    fx = golden(name + ".json")
+    a = ints_to_mont([int(c["a"], 16) for c in fx["cases"]], mod)
+    b = ints_to_mont([int(c["b"], 16) for c in fx["cases"]], mod)
+    for op, key in enumerate(("add", "sub", "mul", "sqr", "neg", "inv")):
+        want = [int(c[key], 16) if c[key] is not None else 0 for c in fx["cases"]]
+        assert mont_to_ints(_field(gpu_ctx, field, op, a, b), mod) == want, key
+
+
+def test_fq2_ops_golden(gpu_ctx):
+    fx = golden("fq2_ops.json")
+    flat = lambda key: ints_to_mont([int(v, 16) for c in fx["cases"] for v in c[key]], Q_MOD).reshape(-1, 8)
+    a, b = flat("a"), flat("b")
+    for op, key in enumerate(("add", "sub", "mul", "sqr", "neg", "inv")):
+        want = [tuple(int(v, 16) for v in c[key]) if c[key] is not None else (0, 0) for c in fx["cases"]]
+        got = mont_to_ints(_field(gpu_ctx, 2, op, a, b).reshape(-1, 4), Q_MOD)
+        assert list(zip(got[0::2], got[1::2])) == want, key
+    nine_u = np.tile(ints_to_mont([9, 1], Q_MOD).reshape(1, 8), (a.shape[0], 1))
+    got = mont_to_ints(_field(gpu_ctx, 2, 2, a, nine_u).reshape(-1, 4), Q_MOD)
+    assert list(zip(got[0::2], got[1::2])) == [tuple(int(v, 16) for v in c["mul_nonresidue"]) for c in fx["cases"]]
+
+
+@pytest.mark.parametrize("name,group", [("g1_ops", 1), ("g2_ops", 2)])
+def test_group_ops_golden(gpu_ctx, name, group):
+    fx = golden(name + ".json")
+    to_m, from_m, w = (g1_to_mont, mont_to_g1, 8) if group == 1 else (g2_to_mont, mont_to_g2, 16)
+
+    def run(op, p, q):
+        p = np.ascontiguousarray(p, dtype=np.uint64)
+        q = np.ascontiguousarray(q, dtype=np.uint64)
+        out = np.zeros_like(p)
+        st = gpu_ctx._lib.zg16_selftest_group(gpu_ctx.handle, group, op, zlib.as_u64p(p), zlib.as_u64p(q), p.shape[0],
+                                              zlib.as_u64p(out))
+        assert st == 0
+        return from_m(out)
+
+    P = [unhex(c["p"]) for c in fx["cases"]]
+    Q = [unhex(c["q"]) for c in fx["cases"]]
+    neg = lambda p: (p[0], (-p[1]) % Q_MOD) if group == 1 else (p[0], ((-p[1][0]) % Q_MOD, (-p[1][1]) % Q_MOD))
+    assert run(0, to_m(P), to_m(P)) == [unhex(c["dbl"]) for c in fx["cases"]]
+    for op in (1, 2):  # mixed and projective addition, including every exceptional case
+        assert run(op, to_m(P), to_m(Q)) == [unhex(c["add"]) for c in fx["cases"]]
+        assert run(op, to_m(P), to_m(P)) == [unhex(c["add_self"]) for c in fx["cases"]]
+        assert run(op, to_m(P), to_m([neg(p) for p in P])) == [None] * len(P)
+        assert run(op, to_m(P), to_m([None] * len(P))) == P
+        assert run(op, to_m([None] * len(P)), to_m(Q)) == Q
+    sm = fx["scalar_mul"]
+    ks = ints_to_mont([int(c["k"], 16) for c in sm["cases"]], R_MOD)
+    pts = to_m([unhex(sm["p"])] * len(sm["cases"]))
+    assert run(3, pts, ks) == [unhex(c["out"]) for c in sm["cases"]]
+
+
+# ------------------------------------------------------------------------------ NTT / H
+@pytest.mark.parametrize("log_n", [4, 5, 6, 7, 8, 9, 10])
+def test_ntt_golden(gpu_ctx, log_n):
+    fx = golden("ntt_%d.json" % log_n)
+    x = ints_to_mont([int(v, 16) for v in fx["input"]], R_MOD)
+    for name, inv, coset in (("fft", 0, 0), ("ifft", 1, 0), ("coset_fft", 0, 1), ("icoset_fft", 1, 1)):
+        assert mont_to_ints(gpu_ctx.ntt(x, inv, coset), R_MOD) == [int(v, 16) for v in fx[name]], name
+
+
+@pytest.mark.parametrize("log_n", [1, 2, 3, 11, 12, 13, 16, 18])
+def test_ntt_vs_cpu_oracle(gpu_ctx, log_n):
+    from oracle import cpu_binding as cb
+    rng = np.random.default_rng(log_n)
+    x = rand_fr(rng, 1 << log_n)
+    for inv, coset in ((0, 0), (1, 0), (0, 1), (1, 1)):
+        assert np.array_equal(gpu_ctx.ntt(x, inv, coset), cb.fft(x, inv, coset, threads=8)), (inv, coset)
+
+
+@pytest.mark.parametrize("log_n", [20, 22])
+def test_ntt_full_size_properties(gpu_ctx, log_n):
+    """Round trip, linearity and the shift theorem at benchmark sizes (no oracle needed)."""
+    rng = np.random.default_rng(7)
+    n = 1 << log_n
+    x = rand_fr(rng, n)
+    fx = gpu_ctx.ntt(x)
+    assert np.array_equal(gpu_ctx.ntt(fx, inverse=True), x)
+    assert np.array_equal(gpu_ctx.ntt(gpu_ctx.ntt(x, coset=True), inverse=True, coset=True), x)
+    # X[0] = sum of inputs: check against a big-integer sum of a strided subsample pattern via linearity
+    e = np.zeros((n, 4), dtype=np.uint64)
+    e[12345 % n] = x[12345 % n]
+    fe = gpu_ctx.ntt(e)  # transform of a single spike: |spectrum| constant => fe[0] equals the spike
+    assert np.array_equal(fe[0], x[12345 % n])
+    y = x.copy()
+    y[12345 % n] = 0
+    fy = gpu_ctx.ntt(y)
+    # linearity: F(x) = F(y) + F(e), checked on a sample of positions with big integers
+    idx = [0, 1, 2, n // 2, n - 1, 777]
+    got = mont_to_ints(fx[idx], R_MOD)
+    want = [(a + b) % R_MOD for a, b in zip(mont_to_ints(fy[idx], R_MOD), mont_to_ints(fe[idx], R_MOD))]
+    assert got == want
+
+
+@pytest.mark.parametrize("rows", [3, 6])
+def test_h_poly_golden(gpu_ctx, rows):
+    fx = golden("h_poly_%d.json" % rows)
+    a, b, c = (ints_to_mont([int(v, 16) for v in fx[k]], R_MOD) for k in "abc")
+    h, m = gpu_ctx.h_coefficients(a, b, c)
+    assert m == fx["m"] and mont_to_ints(h, R_MOD) == [int(v, 16) for v in fx["h"]]
+
+
+@pytest.mark.parametrize("rows", [1000, 5000, (1 << 15) + 3])
+def test_h_poly_vs_cpu_oracle(gpu_ctx, rows):
+    from oracle import cpu_binding as cb
+    rng = np.random.default_rng(rows)
+    a, b, c = (rand_fr(rng, rows) for _ in range(3))
+    h, m = gpu_ctx.h_coefficients(a, b, c)
+    h2, m2 = cb.h_coefficients(a, b, c, threads=8)
+    assert m == m2 and np.array_equal(h, h2)
+
+
+# ------------------------------------------------------------------------------ multiexp
+@pytest.mark.parametrize("name,group", [("msm_g1_4", "g1"), ("msm_g1_8", "g1"), ("msm_g1_12", "g1"),
+                                        ("msm_g2_4", "g2"), ("msm_g2_8", "g2")])
+def test_msm_golden(gpu_ctx, name, group):
+    fx = golden(name + ".json")
+    to_m, from_m, fn = (g1_to_mont, mont_to_g1, gpu_ctx.msm_g1) if group == "g1" else (g2_to_mont, mont_to_g2, gpu_ctx.msm_g2)
+    bases = [unhex(p) for p in fx["bases"]]
+    sc = ints_to_mont([int(v, 16) for v in fx["scalars"]], R_MOD)
+    assert from_m(fn(to_m(bases), sc))[0] == unhex(fx["result"])
+    dens = np.array(fx["density"], dtype=np.uint8)
+    assert from_m(fn(to_m([p for p, d in zip(bases, dens) if d]), sc, dens))[0] == unhex(fx["result_density"])
+
+
+def test_msm_edge_cases(gpu_ctx):
+    from oracle import bn254 as O
+    G = O.G1_GEN
+    empty8, empty4 = np.zeros((0, 8), np.uint64), np.zeros((0, 4), np.uint64)
+    assert mont_to_g1(gpu_ctx.msm_g1(empty8, empty4))[0] is None                                   # empty
+    assert mont_to_g1(gpu_ctx.msm_g1(g1_to_mont([G] * 5), ints_to_mont([0] * 5, R_MOD)))[0] is None  # all zero
+    want = O.G1.to_affine(O.G1.mul(O.G1.gen, 700))
+    assert mont_to_g1(gpu_ctx.msm_g1(g1_to_mont([G] * 700), ints_to_mont([1] * 700, R_MOD)))[0] == want  # all ones
+    assert mont_to_g1(gpu_ctx.msm_g1(g1_to_mont([G, G]), ints_to_mont([5, R_MOD - 5], R_MOD)))[0] is None  # cancels
+    want = O.G1.to_affine(O.G1.mul(O.G1.gen, (R_MOD - 1) * 3 % R_MOD))
+    assert mont_to_g1(gpu_ctx.msm_g1(g1_to_mont([G] * 3), ints_to_mont([R_MOD - 1] * 3, R_MOD)))[0] == want  # max scalar
+    # a cleared density bit skips the scalar without consuming a base
+    dens = np.array([1, 0, 1], dtype=np.uint8)
+    got = mont_to_g1(gpu_ctx.msm_g1(g1_to_mont([G, G]), ints_to_mont([2, 1000, 3], R_MOD), dens))[0]
+    assert got == O.G1.to_affine(O.G1.mul(O.G1.gen, 5))
+    # an identity base consumed by a non-zero scalar is bellman's UnexpectedIdentity; by a zero scalar it is not
+    with pytest.raises(SynthesisError) as e:
+        gpu_ctx.msm_g1(g1_to_mont([G, None]), ints_to_mont([2, 3], R_MOD))
+    assert e.value.status_name == "UnexpectedIdentity"
+    with pytest.raises(SynthesisError):
+        gpu_ctx.msm_g1(g1_to_mont([G, None]), ints_to_mont([2, 1], R_MOD))
+    assert mont_to_g1(gpu_ctx.msm_g1(g1_to_mont([G, None]), ints_to_mont([2, 0], R_MOD)))[0] == O.G1.to_affine(O.G1.mul(O.G1.gen, 2))
+    with pytest.raises(SynthesisError) as e:
+        gpu_ctx.msm_g1(g1_to_mont([G]), ints_to_mont([2, 3], R_MOD))
+    assert e.value.status_name == "InvalidArgument"
+
+
+@pytest.mark.parametrize("group,n", [("g1", 1 << 14), ("g1", 50000), ("g2", 1 << 12)])
+def test_msm_vs_cpu_oracle(gpu_ctx, group, n):
+    """Seeded bases k_i*G (built by the GPU fixed-base multiplier), skewed scalars (zinc-like)."""
+    from oracle import cpu_binding as cb
+    from zinc_amd import workload
+    rng = np.random.default_rng(n)
+    g1gen, g2gen = workload._generators()
+    ks = rand_fr(rng, n)
+    bases = workload.fixed_base_g1(gpu_ctx, g1gen, ks) if group == "g1" else workload.fixed_base_g2(gpu_ctx, g2gen, ks)
+    sc = rand_fr(rng, n)
+    one = ints_to_mont([1], R_MOD)[0]
+    kind = rng.integers(0, 10, size=n)
+    sc[kind < 2] = 0
+    sc[(kind >= 2) & (kind < 6)] = one
+    small = ints_to_mont([int(v) for v in rng.integers(2, 300, size=64)], R_MOD)
+    sc[kind == 6] = small[rng.integers(0, 64, size=int((kind == 6).sum()))]
+    dens = (rng.integers(0, 4, size=n) != 0).astype(np.uint8)
+    fn = gpu_ctx.msm_g1 if group == "g1" else gpu_ctx.msm_g2
+    st, want = cb.multiexp(group, bases, sc, None, threads=8)
+    assert st == 0 and np.array_equal(fn(bases, sc), want)
+    st, want = cb.multiexp(group, bases[dens != 0], sc, dens, threads=8)
+    assert st == 0 and np.array_equal(fn(bases[dens != 0], sc, dens), want)
+
+
+def test_msm_full_size_linearity(gpu_ctx):
+    """2^20 points: msm(s) + msm(t) == msm(s + t) and msm(k*s) == k*msm(s), via 3-term multiexps."""
+    from zinc_amd import workload
+    rng = np.random.default_rng(99)
+    n = 1 << 20
+    g1gen, _ = workload._generators()
+    bases = workload.fixed_base_g1(gpu_ctx, g1gen, rand_fr(rng, n))
+    s = rand_fr(rng, n)
+    t = rand_fr(rng, n)
+    s_plus_t = _field(gpu_ctx, 0, 0, s, t)
+    ps, pt, pst = gpu_ctx.msm_g1(bases, s), gpu_ctx.msm_g1(bases, t), gpu_ctx.msm_g1(bases, s_plus_t)
+    one = ints_to_mont([1, 1], R_MOD)
+    assert np.array_equal(gpu_ctx.msm_g1(np.stack([ps, pt]), one), pst)
+    k = ints_to_mont([0xABCDEF12345], R_MOD)
+    ks = _field(gpu_ctx, 0, 2, s, np.tile(k, (n, 1)))
+    assert np.array_equal(gpu_ctx.msm_g1(bases, ks), gpu_ctx.msm_g1(ps.reshape(1, 8), k))
+
+
+# ------------------------------------------------------------------------------ SpMV / prove
+@pytest.mark.parametrize("idx", [1, 2, 3])
+def test_prove_golden(gpu_ctx, idx):
+    fx = golden("prove_tiny_%d.json" % idx)
+    circ, key = FixtureCircuit(fx), FixtureKey(fx)
+    pa = ProvingAssignment()
+    pa.alloc_input(1)
+    circ.synthesize(pa)
+    pa.finalize_inputs()
+    mat = pa.r1cs().upload(gpu_ctx)
+    zi, za = pa.witness()
+    a, b, c = mat.spmv(zi, za)
+    assert mont_to_ints(a, R_MOD) == [int(v, 16) for v in fx["eval_a"]]
+    assert mont_to_ints(b, R_MOD) == [int(v, 16) for v in fx["eval_b"]]
+    assert mont_to_ints(c, R_MOD) == [int(v, 16) for v in fx["eval_c"]]
+    assert mat.density() == (sum(fx["a_aux_density"]), sum(fx["b_input_density"]), sum(fx["b_aux_density"]))
+    mat.free()
+    proof = create_proof(circ, Parameters.from_points(key), int(fx["r"], 16), int(fx["s"], 16), gpu_ctx)
+    assert proof.as_tuple() == fixture_proof(fx)
+    from zinc_amd import codec
+    assert codec.proof_write(proof.as_tuple()).hex() == fx["proof_bytes"]
+
+
+@pytest.mark.parametrize("log_rows,dense", [(10, False), (12, True), (14, False), (16, False)])
+def test_prove_vs_cpu_oracle(gpu_ctx, log_rows, dense):
+    """Seeded zinc-shaped circuits: GPU proof == proof of the CPU restatement of bellman, bit for bit."""
+    from oracle import cpu_binding as cb
+    from zinc_amd import workload
+    circ = workload.SyntheticCircuit(1 << log_rows, dense=dense, seed=(log_rows, 2, 3, 4))
+    params = workload.generate_parameters(gpu_ctx, circ, dict(k1=5, k2=7, alpha=11, beta=13, gamma=17, delta=19, tau=23 + log_rows))
+    r1cs = circ.r1cs()
+    zi, za = circ.witness()
+    rs = ints_to_mont([0x123456789, 0x987654321], R_MOD)
+    st, want, _ = cb.prove(params, r1cs, zi, za, rs[0], rs[1], threads=8)
+    assert st == 0
+    key, mat = params.upload(gpu_ctx), r1cs.upload(gpu_ctx)
+    (ea, eb, ec), _ = cb.eval_rows(r1cs, zi, za)
+    ga, gb, gc = mat.spmv(zi, za)
+    assert np.array_equal(ga, ea) and np.array_equal(gb, eb) and np.array_equal(gc, ec)
+    got = prove_recorded(gpu_ctx, key, mat, zi, za, rs[0], rs[1])
+    for g, w in zip((got.raw.a, got.raw.b, got.raw.c), want):
+        assert np.array_equal(np.frombuffer(bytes(g), dtype=np.uint64), w)
+    # the two-shard path gives the same proof (what two GPUs would compute, run back to back here)
+    from zinc_amd.distributed import finish
+    parts = (zlib.Partial * 2)()
+    for i in range(2):
+        shard = params.upload(gpu_ctx, i, 2)
+        st = gpu_ctx._lib.zg16_prove_partial(gpu_ctx.handle, shard.handle, mat.handle, zi.ctypes.data_as(C.c_void_p),
+                                             za.ctypes.data_as(C.c_void_p), 0, C.byref(parts[i]))
+        assert st == 0
+        shard.free()
+    pv = params.view()
+    p2 = finish(pv, parts, 2, rs[0], rs[1])
+    assert bytes(p2) == bytes(got.raw)
+    key.free()
+    mat.free()
+
+
+def test_prove_full_size_verifies(gpu_ctx):
+    """2^20 rows (the benchmark workload): the proof satisfies the Groth16 pairing equation, is
+    reproducible, and changes with r."""
+    from oracle import bn254 as O, groth16 as G
+    from zinc_amd import workload
+    circ = workload.SyntheticCircuit(1 << 20)
+    params = workload.generate_parameters(gpu_ctx, circ, dict(k1=3, k2=5, alpha=7, beta=11, gamma=13, delta=17, tau=0xC0FFEE))
+    key, mat = params.upload(gpu_ctx), circ.r1cs().upload(gpu_ctx)
+    zi, za = circ.witness()
+    rs = ints_to_mont([0xDEADBEEF, 0xFEEDFACE, 0xDEADBEF0], R_MOD)
+    p1 = prove_recorded(gpu_ctx, key, mat, zi, za, rs[0], rs[1])
+    p2 = prove_recorded(gpu_ctx, key, mat, zi, za, rs[0], rs[1])
+    p3 = prove_recorded(gpu_ctx, key, mat, zi, za, rs[2], rs[1])
+    assert p1.as_tuple() == p2.as_tuple() != p3.as_tuple()
+
+    class VK:
+        pass
+    vk = VK()
+    vk.alpha_g1, vk.delta_g1 = mont_to_g1(params.alpha_g1)[0], mont_to_g1(params.delta_g1)[0]
+    vk.beta_g2, vk.delta_g2, vk.gamma_g2 = (mont_to_g2(x)[0] for x in (params.beta_g2, params.delta_g2, params.gamma_g2))
+    vk.ic = mont_to_g1(params.ic)
+    public = mont_to_ints(zi[1:], R_MOD)
+    assert G.verify_proof(vk, p1.as_tuple(), public)
+    assert G.verify_proof(vk, p3.as_tuple(), public)
+    assert not G.verify_proof(vk, p1.as_tuple(), [(public[0] + 1) % R_MOD] + public[1:])
+    key.free()
+    mat.free()
+
+
+# ------------------------------------------------------------------------------ error behaviour
+def test_error_statuses(gpu_ctx):
+    lib = gpu_ctx._lib
+    buf = np.zeros((2, 4), dtype=np.uint64)
+    assert lib.zg16_ntt(gpu_ctx.handle, buf.ctypes.data_as(C.c_void_p), 28, 0, 0, 0) == 1  # PolynomialDegreeTooLarge
+    assert b"2^27" in lib.zg16_last_error(gpu_ctx.handle)
+    fx = golden("prove_tiny_1.json")
+    circ, key = FixtureCircuit(fx), FixtureKey(fx)
+    pa = ProvingAssignment()
+    pa.alloc_input(1)
+    circ.synthesize(pa)
+    pa.finalize_inputs()
+    zi, za = pa.witness()
+    rs = ints_to_mont([1, 2], R_MOD)
+    mat = pa.r1cs().upload(gpu_ctx)
+    # a key whose l query is one point short
+    short = Parameters.from_points(key)
+    short.l = short.l[:-1].copy()
+    dk = short.upload(gpu_ctx)
+    with pytest.raises(SynthesisError) as e:
+        prove_recorded(gpu_ctx, dk, mat, zi, za, rs[0], rs[1])
+    assert e.value.status_name == "MalformedKey"
+    dk.free()
+    # delta at infinity
+    bad = Parameters.from_points(key)
+    bad.delta_g1 = np.zeros((1, 8), dtype=np.uint64)
+    dk = bad.upload(gpu_ctx)
+    with pytest.raises(SynthesisError) as e:
+        prove_recorded(gpu_ctx, dk, mat, zi, za, rs[0], rs[1])
+    assert e.value.status_name == "UnexpectedIdentity"
+    dk.free()
+    # missing witness
+    dk = Parameters.from_points(key).upload(gpu_ctx)
+    proof = zlib.Proof()
+    st = lib.zg16_prove(gpu_ctx.handle, dk.handle, mat.handle, None, None, 0, zlib.as_u64p(rs[0]), zlib.as_u64p(rs[1]),
+                        C.byref(proof))
+    assert st == 3  # AssignmentMissing
+    dk.free()
+    mat.free()
+    # a column that names a variable the circuit does not have
+    r = pa.r1cs()
+    rp, col, co = r.mats[0]
+    col = col.copy()
+    col[0] = 0x80000000 | 5000
+    with pytest.raises(SynthesisError) as e:
+        R1CS(r.n_inputs, r.n_aux, [(rp, col, co), r.mats[1], r.mats[2]]).upload(gpu_ctx)
+    assert e.value.status_name == "InvalidArgument"

@@ -1,0 +1,146 @@
+"""CPU: host-side logic -- ABI surface, recorder, codecs, workload generator, sharding, gloo gather."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden, unhex, FixtureCircuit, FixtureKey, fixture_proof
+from zinc_amd import codec, lib as zlib
+from zinc_amd.fields import R_MOD, ints_to_mont, mont_to_ints
+from zinc_amd.groth16 import ProvingAssignment, AUX, random_fr
+from zinc_amd.distributed import shard_range
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "zinc_groth16.h")).read()
+    return sorted(set(re.findall(r"\b(zg16_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = header_symbols()
+    assert len(names) >= 20
+    lib = zlib.load()
+    for n in names:
+        assert hasattr(lib, n), "include/zinc_groth16.h declares %s but the library does not export it" % n
+    bound = {n for n, _, _ in zlib.SYMBOLS}
+    assert bound == set(names), "ctypes table and header disagree: %s" % (bound ^ set(names))
+
+
+def test_header_compiles_as_c():
+    src = '#include "zinc_groth16.h"\nint main(void){zg16_proof p; (void)p; return sizeof(zg16_partial) == 640 ? 0 : 1;}\n'
+    exe = os.path.join(ROOT, "build", "hdr_check")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-x", "c", "-", "-o", exe],
+                   input=src.encode(), check=True)
+    assert subprocess.run([exe]).returncode == 0
+    assert C.sizeof(zlib.Partial) == 640 and C.sizeof(zlib.Proof) == 256
+
+
+def test_recorder_builds_canonical_csr():
+    fx = golden("prove_tiny_2.json")
+    circ = FixtureCircuit(fx)
+    pa = ProvingAssignment()
+    assert pa.alloc_input(1) == 0 == ProvingAssignment.one()
+    circ.synthesize(pa)
+    pa.finalize_inputs()
+    r = pa.r1cs()
+    n_rows = len(circ.rows[0]) + circ.n_in
+    assert r.n_rows == n_rows and r.n_inputs == circ.n_in and r.n_aux == circ.n_aux
+    rp, col, co = r.mats[0]
+    # the appended rows are `input_i * 0 = 0`: one A term with coefficient one, empty B and C
+    for i in range(circ.n_in):
+        row = len(circ.rows[0]) + i
+        assert rp[row + 1] - rp[row] == 1 and col[rp[row]] == i
+        assert mont_to_ints(co[rp[row]], R_MOD) == [1]
+    assert r.mats[1][0][-1] == sum(len(lc) for lc in circ.rows[1])
+    # aux columns carry bit 31
+    cols = [int(c) for c in col]
+    assert any(c & AUX for c in cols) and all((c & ~AUX) < max(circ.n_aux, circ.n_in) for c in cols)
+
+
+@pytest.mark.parametrize("idx", [1, 2, 3])
+def test_proof_codec_golden(idx):
+    fx = golden("prove_tiny_%d.json" % idx)
+    proof = fixture_proof(fx)
+    data = codec.proof_write(proof)
+    assert len(data) == 128 and data.hex() == fx["proof_bytes"]
+    assert codec.proof_read(data) == proof
+    with pytest.raises(codec.DecodeError):
+        codec.proof_read(data[:-1])
+
+
+def test_params_codec_roundtrip_and_checks():
+    key = FixtureKey(golden("prove_tiny_1.json"))
+    data = codec.params_write(key)
+    back = codec.params_read(data, checked=True)
+    for name in ("alpha_g1", "beta_g2", "gamma_g2", "delta_g1", "ic", "h", "l", "a", "b_g1", "b_g2"):
+        assert getattr(back, name) == getattr(key, name), name
+    assert data[:len(codec.vk_write(key))] == codec.vk_write(key)
+    # infinity in a query vector is rejected when checked, accepted otherwise
+    key.h[0] = None
+    bad = codec.params_write(key)
+    with pytest.raises(codec.DecodeError):
+        codec.params_read(bad, checked=True)
+    assert codec.params_read(bad, checked=False).h[0] is None
+    # an off-curve point
+    ba = bytearray(data)
+    ba[63] ^= 1
+    with pytest.raises(codec.DecodeError):
+        codec.params_read(bytes(ba), checked=True)
+    assert codec.g1_read(codec.g1_write(None, True), True) is None
+    assert codec.g2_read(codec.g2_write(None, False), False) is None
+
+
+def test_random_fr_follows_reference_rng():
+    from oracle.xorshift import XorShiftRng
+    fx = golden("rng_xorshift.json")
+    rng = XorShiftRng(tuple(fx["seed"]))
+    want = [int(x, 16) * pow(1 << 256, -1, R_MOD) % R_MOD for x in fx["fr_first8"]]
+    assert [random_fr(rng) for _ in range(8)] == want
+    assert 0 <= random_fr() < R_MOD
+
+
+def test_synthetic_workload_is_satisfied_and_canonical():
+    from zinc_amd.workload import SyntheticCircuit
+    for dense in (False, True):
+        c = SyntheticCircuit(1 << 12, n_pub=16, dense=dense)
+        assert c.n_rows == 4096 and c.n_inputs == 17 and c.satisfied()
+        r = c.r1cs()
+        for rp, col, co in r.mats:
+            assert rp[0] == 0 and np.all(np.diff(rp.astype(np.int64)) >= 0) and rp[-1] == col.shape[0]
+            assert co.any(axis=1).all(), "zero coefficient emitted"
+            for row in range(0, r.n_rows, 97):  # inputs first then aux, strictly ascending, no repeats
+                cols = col[rp[row]:rp[row + 1]].astype(np.int64)
+                assert np.all(np.diff(cols) > 0)
+        zi, za = c.witness()
+        assert mont_to_ints(zi[:1], R_MOD) == [1]
+        bits = sum(1 for v in mont_to_ints(za[:2000], R_MOD) if v in (0, 1))
+        assert (bits < 50) if dense else (bits > 1200)
+    # same seed, same circuit
+    a, b = SyntheticCircuit(1 << 10), SyntheticCircuit(1 << 10)
+    assert np.array_equal(a.witness()[1], b.witness()[1])
+    assert not np.array_equal(a.witness()[1], SyntheticCircuit(1 << 10, seed=(9, 8, 7, 6)).witness()[1])
+
+
+def test_shard_ranges_partition_every_query():
+    for n in (0, 1, 7, 1000, (1 << 20) - 1):
+        for cnt in (1, 2, 3, 8):
+            spans = [shard_range(n, i, cnt) for i in range(cnt)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(cnt - 1))
+
+
+def test_two_rank_gloo_gather_and_finish():
+    """world_size 2 over gloo: each rank sums its half of every query (on the CPU here), the partials
+    are all-gathered and rank 0 assembles the proof -- must equal the single-process proof."""
+    script = os.path.join(ROOT, "tests", "gloo_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", PYTHONPATH=ROOT)
+    procs = [subprocess.Popen([sys.executable, script, str(r), "2"], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "PROOF_MATCH" in outs[0], outs[0]

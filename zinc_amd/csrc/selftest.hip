@@ -1,0 +1,102 @@
+// Element-wise device evaluation of the field and group primitives, so that parity tests can pin
+// them (edge cases included) against golden vectors through the C ABI.  Not used while proving.
+#include <string.h>
+
+#include "common.cuh"
+
+namespace zg {
+
+template <class T>
+ZG_D T field_op(int op, const T& a, const T& b) {
+  switch (op) {
+    case 0: return add(a, b);
+    case 1: return sub(a, b);
+    case 2: return mul(a, b);
+    case 3: return sqr(a);
+    case 4: return neg(a);
+    default: return a.is_zero() ? a : inv(a);
+  }
+}
+
+template <class T>
+__global__ void k_field_op(int op, const T* a, const T* b, T* out, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = field_op(op, a[i], b[i]);
+}
+
+template <class F>
+__global__ void k_group_op(int op, const Affine<F>* p, const void* q, Affine<F>* out, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  XYZZ<F> acc = XYZZ<F>::from_affine(p[i]);
+  if (op == 0) {
+    acc = dbl(acc);
+  } else if (op == 1) {
+    add_mixed(acc, ((const Affine<F>*)q)[i]);
+  } else if (op == 2) {
+    // route the second operand through a non-trivial XYZZ representation (2q - q)
+    const Affine<F> qa = ((const Affine<F>*)q)[i];
+    XYZZ<F> t = dbl(XYZZ<F>::from_affine(qa));
+    add_mixed(t, neg(qa));
+    add_full(acc, t);
+  } else {
+    const Fr k = from_mont(((const Fr*)q)[i]);
+    acc = scalar_mul(acc, k.v);
+  }
+  out[i] = to_affine(acc);
+}
+
+template <class T>
+static zg16_status run_field(zg16_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
+  char* buf;
+  const size_t bytes = n * sizeof(T);
+  ZG_TRY(scratch_get(ctx, 5, 3 * bytes + 768, (void**)&buf));
+  T *da = (T*)buf, *db = (T*)(buf + ((bytes + 255) & ~(size_t)255)), *dout = (T*)(buf + 2 * ((bytes + 255) & ~(size_t)255));
+  ZG_HIP(ctx, hipMemcpyAsync(da, a, bytes, hipMemcpyHostToDevice, ctx->stream));
+  ZG_HIP(ctx, hipMemcpyAsync(db, b ? b : a, bytes, hipMemcpyHostToDevice, ctx->stream));
+  k_field_op<T><<<(unsigned)((n + 63) / 64), 64, 0, ctx->stream>>>(op, da, db, dout, (uint32_t)n);
+  ZG_HIP(ctx, hipGetLastError());
+  ZG_HIP(ctx, hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ZG16_OK;
+}
+
+template <class F>
+static zg16_status run_group(zg16_ctx* ctx, int op, const uint64_t* p, const uint64_t* q, size_t n, uint64_t* out) {
+  char* buf;
+  const size_t pb = n * sizeof(Affine<F>), qb = op == 3 ? n * sizeof(Fr) : pb;
+  const size_t pa = (pb + 255) & ~(size_t)255, qa = (qb + 255) & ~(size_t)255;
+  ZG_TRY(scratch_get(ctx, 5, 2 * pa + qa + 256, (void**)&buf));
+  ZG_HIP(ctx, hipMemcpyAsync(buf, p, pb, hipMemcpyHostToDevice, ctx->stream));
+  if (op != 0) ZG_HIP(ctx, hipMemcpyAsync(buf + pa, q, qb, hipMemcpyHostToDevice, ctx->stream));
+  k_group_op<F><<<(unsigned)((n + 63) / 64), 64, 0, ctx->stream>>>(op, (const Affine<F>*)buf, buf + pa,
+                                                                  (Affine<F>*)(buf + pa + qa), (uint32_t)n);
+  ZG_HIP(ctx, hipGetLastError());
+  ZG_HIP(ctx, hipMemcpyAsync(out, buf + pa + qa, pb, hipMemcpyDeviceToHost, ctx->stream));
+  ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ZG16_OK;
+}
+
+}  // namespace zg
+
+extern "C" {
+
+zg16_status zg16_selftest_field(zg16_ctx* ctx, int field, int op, const uint64_t* a, const uint64_t* b, size_t n,
+                                uint64_t* out) {
+  if (!ctx || !a || !out || !n || op < 0 || op > 5 || n > (1u << 24)) return zg::fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "bad selftest arguments");
+  ZG_HIP(ctx, hipSetDevice(ctx->device));
+  if (field == 0) return zg::run_field<zg::Fr>(ctx, op, a, b, n, out);
+  if (field == 1) return zg::run_field<zg::Fq>(ctx, op, a, b, n, out);
+  if (field == 2) return zg::run_field<zg::Fq2>(ctx, op, a, b, n, out);
+  return zg::fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "unknown field %d", field);
+}
+
+zg16_status zg16_selftest_group(zg16_ctx* ctx, int group, int op, const uint64_t* p, const uint64_t* q, size_t n,
+                                uint64_t* out) {
+  if (!ctx || !p || !out || !n || op < 0 || op > 3 || (op && !q) || n > (1u << 24)) return zg::fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "bad selftest arguments");
+  ZG_HIP(ctx, hipSetDevice(ctx->device));
+  if (group == 1) return zg::run_group<zg::Fq>(ctx, op, p, q, n, out);
+  if (group == 2) return zg::run_group<zg::Fq2>(ctx, op, p, q, n, out);
+  return zg::fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "unknown group %d", group);
+}
+}

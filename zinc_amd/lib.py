@@ -83,6 +83,8 @@ SYMBOLS = [
     ("zg16_spmv", C.c_int, [C.c_void_p, C.c_void_p, u64p, u64p, u64p, u64p, u64p]),
     ("zg16_fixed_base_g1", C.c_int, [C.c_void_p, u64p, u64p, C.c_size_t, u64p]),
     ("zg16_fixed_base_g2", C.c_int, [C.c_void_p, u64p, u64p, C.c_size_t, u64p]),
+    ("zg16_selftest_field", C.c_int, [C.c_void_p, C.c_int, C.c_int, u64p, u64p, C.c_size_t, u64p]),
+    ("zg16_selftest_group", C.c_int, [C.c_void_p, C.c_int, C.c_int, u64p, u64p, C.c_size_t, u64p]),
     ("zg16_profile_enable", C.c_int, [C.c_void_p, C.c_int]),
     ("zg16_profile_reset", C.c_int, [C.c_void_p]),
     ("zg16_profile_kernel_count", C.c_int, []),
