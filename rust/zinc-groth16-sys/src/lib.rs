@@ -1,0 +1,148 @@
+//! FFI binding of `include/zinc_groth16.h` plus `create_random_proof`, a drop-in for
+//! `franklin_crypto::bellman::groth16::create_random_proof` at
+//! zinc-vm/src/core/circuit/facade.rs:153 and zinc-vm/src/core/contract/facade.rs:387.
+//!
+//! NOT COMPILED IN THIS REPOSITORY'S ENVIRONMENT (no Rust toolchain): kept as the source a zinc-vm
+//! maintainer adds.  Field elements are passed as-is: ff_ce's `Fr` is `#[repr]`-compatible with
+//! 4 little-endian u64 Montgomery limbs, which is the ABI's element layout.
+#![allow(non_camel_case_types)]
+use franklin_crypto::bellman::groth16::{Parameters, Proof};
+use franklin_crypto::bellman::pairing::bn256::{Bn256, Fr, G1Affine, G2Affine};
+use franklin_crypto::bellman::pairing::ff::{Field, PrimeField};
+use franklin_crypto::bellman::pairing::CurveAffine;
+use franklin_crypto::bellman::{Circuit, ConstraintSystem, Index, LinearCombination, SynthesisError, Variable};
+use rand::Rng;
+use std::os::raw::{c_char, c_int, c_void};
+
+#[repr(C)] pub struct zg16_ctx { _p: [u8; 0] }
+#[repr(C)] pub struct zg16_pk { _p: [u8; 0] }
+#[repr(C)] pub struct zg16_r1cs { _p: [u8; 0] }
+
+#[repr(C)]
+pub struct zg16_pk_view {
+    pub alpha_g1: *const u64, pub beta_g1: *const u64, pub beta_g2: *const u64,
+    pub delta_g1: *const u64, pub delta_g2: *const u64,
+    pub h: *const u64, pub n_h: usize, pub l: *const u64, pub n_l: usize,
+    pub a: *const u64, pub n_a: usize, pub b_g1: *const u64, pub n_b_g1: usize,
+    pub b_g2: *const u64, pub n_b_g2: usize,
+}
+#[repr(C)] pub struct zg16_csr { pub row_ptr: *const u64, pub col: *const u32, pub coeff: *const u64 }
+#[repr(C)]
+pub struct zg16_r1cs_view { pub n_rows: usize, pub n_inputs: usize, pub n_aux: usize, pub a: zg16_csr, pub b: zg16_csr, pub c: zg16_csr }
+#[repr(C)] pub struct zg16_proof { pub a: [u64; 8], pub b: [u64; 16], pub c: [u64; 8] }
+
+extern "C" {
+    pub fn zg16_ctx_create(device_id: c_int, out: *mut *mut zg16_ctx) -> c_int;
+    pub fn zg16_ctx_destroy(ctx: *mut zg16_ctx);
+    pub fn zg16_last_error(ctx: *const zg16_ctx) -> *const c_char;
+    pub fn zg16_pk_upload(ctx: *mut zg16_ctx, view: *const zg16_pk_view, shard_index: c_int, shard_count: c_int, out: *mut *mut zg16_pk) -> c_int;
+    pub fn zg16_pk_free(pk: *mut zg16_pk);
+    pub fn zg16_r1cs_upload(ctx: *mut zg16_ctx, view: *const zg16_r1cs_view, out: *mut *mut zg16_r1cs) -> c_int;
+    pub fn zg16_r1cs_free(r: *mut zg16_r1cs);
+    pub fn zg16_prove(ctx: *mut zg16_ctx, pk: *const zg16_pk, r1cs: *const zg16_r1cs, z_in: *const c_void, z_aux: *const c_void,
+                      witness_on_device: c_int, r: *const u64, s: *const u64, out: *mut zg16_proof) -> c_int;
+}
+
+/// Plays the role of bellman's `ProvingAssignment`, but records the matrices instead of evaluating
+/// rows on the host.  Sits *below* zinc-vm's `DedupCS(LoggingCS(cs))` wrappers
+/// (zinc-vm/src/core/circuit/synthesizer.rs:34), so every row arrives in canonical form.
+pub struct RecordingAssignment {
+    pub z_in: Vec<Fr>, pub z_aux: Vec<Fr>,
+    row_ptr: [Vec<u64>; 3], col: [Vec<u32>; 3], coeff: [Vec<Fr>; 3],
+}
+
+impl RecordingAssignment {
+    pub fn new() -> Self {
+        RecordingAssignment { z_in: vec![], z_aux: vec![], row_ptr: [vec![0], vec![0], vec![0]], col: Default::default(), coeff: Default::default() }
+    }
+    fn push(&mut self, k: usize, lc: &LinearCombination<Bn256>) {
+        for (var, coeff) in lc.as_ref() {
+            let c = match var.get_unchecked() { Index::Input(i) => i as u32, Index::Aux(i) => (i as u32) | 0x8000_0000 };
+            self.col[k].push(c);
+            self.coeff[k].push(*coeff);
+        }
+        self.row_ptr[k].push(self.col[k].len() as u64);
+    }
+}
+
+impl ConstraintSystem<Bn256> for RecordingAssignment {
+    type Root = Self;
+    fn alloc<F, A, AR>(&mut self, _: A, f: F) -> Result<Variable, SynthesisError>
+    where F: FnOnce() -> Result<Fr, SynthesisError>, A: FnOnce() -> AR, AR: Into<String> {
+        self.z_aux.push(f()?);
+        Ok(Variable::new_unchecked(Index::Aux(self.z_aux.len() - 1)))
+    }
+    fn alloc_input<F, A, AR>(&mut self, _: A, f: F) -> Result<Variable, SynthesisError>
+    where F: FnOnce() -> Result<Fr, SynthesisError>, A: FnOnce() -> AR, AR: Into<String> {
+        self.z_in.push(f()?);
+        Ok(Variable::new_unchecked(Index::Input(self.z_in.len() - 1)))
+    }
+    fn enforce<A, AR, LA, LB, LC>(&mut self, _: A, a: LA, b: LB, c: LC)
+    where A: FnOnce() -> AR, AR: Into<String>,
+          LA: FnOnce(LinearCombination<Bn256>) -> LinearCombination<Bn256>,
+          LB: FnOnce(LinearCombination<Bn256>) -> LinearCombination<Bn256>,
+          LC: FnOnce(LinearCombination<Bn256>) -> LinearCombination<Bn256> {
+        let (a, b, c) = (a(LinearCombination::zero()), b(LinearCombination::zero()), c(LinearCombination::zero()));
+        self.push(0, &a); self.push(1, &b); self.push(2, &c);
+    }
+    fn push_namespace<NR, N>(&mut self, _: N) where NR: Into<String>, N: FnOnce() -> NR {}
+    fn pop_namespace(&mut self) {}
+    fn get_root(&mut self) -> &mut Self::Root { self }
+}
+
+fn g1(p: &G1Affine) -> [u64; 8] { if p.is_zero() { [0; 8] } else { let (x, y) = p.into_xy_unchecked(); unsafe { std::mem::transmute([x, y]) } } }
+fn g2(p: &G2Affine) -> [u64; 16] { if p.is_zero() { [0; 16] } else { let (x, y) = p.into_xy_unchecked(); unsafe { std::mem::transmute([x, y]) } } }
+
+fn status_to_error(st: c_int) -> SynthesisError {
+    match st {
+        1 => SynthesisError::PolynomialDegreeTooLarge,
+        2 => SynthesisError::UnexpectedIdentity,
+        3 => SynthesisError::AssignmentMissing,
+        4 => SynthesisError::MalformedVerifyingKey,
+        _ => SynthesisError::IoError(std::io::Error::new(std::io::ErrorKind::Other, "zinc_groth16_hip device error")),
+    }
+}
+
+/// Same signature shape and semantics as bellman's `create_proof`.
+pub fn create_proof<C: Circuit<Bn256>>(circuit: C, params: &Parameters<Bn256>, r: Fr, s: Fr) -> Result<Proof<Bn256>, SynthesisError> {
+    let mut cs = RecordingAssignment::new();
+    cs.alloc_input(|| "", || Ok(Fr::one()))?;
+    circuit.synthesize(&mut cs)?;
+    for i in 0..cs.z_in.len() {
+        cs.enforce(|| "", |lc| lc + Variable::new_unchecked(Index::Input(i)), |lc| lc, |lc| lc);
+    }
+    let conv1 = |v: &Vec<G1Affine>| v.iter().map(g1).collect::<Vec<_>>();
+    let (h, l, a, b1) = (conv1(&params.h), conv1(&params.l), conv1(&params.a), conv1(&params.b_g1));
+    let b2: Vec<[u64; 16]> = params.b_g2.iter().map(g2).collect();
+    let (al, be1, de1) = (g1(&params.vk.alpha_g1), g1(&params.vk.beta_g1), g1(&params.vk.delta_g1));
+    let (be2, de2) = (g2(&params.vk.beta_g2), g2(&params.vk.delta_g2));
+    let pkv = zg16_pk_view { alpha_g1: al.as_ptr(), beta_g1: be1.as_ptr(), beta_g2: be2.as_ptr(), delta_g1: de1.as_ptr(), delta_g2: de2.as_ptr(),
+        h: h.as_ptr() as *const u64, n_h: h.len(), l: l.as_ptr() as *const u64, n_l: l.len(), a: a.as_ptr() as *const u64, n_a: a.len(),
+        b_g1: b1.as_ptr() as *const u64, n_b_g1: b1.len(), b_g2: b2.as_ptr() as *const u64, n_b_g2: b2.len() };
+    let csr = |k: usize| zg16_csr { row_ptr: cs.row_ptr[k].as_ptr(), col: cs.col[k].as_ptr(), coeff: cs.coeff[k].as_ptr() as *const u64 };
+    let rv = zg16_r1cs_view { n_rows: cs.row_ptr[0].len() - 1, n_inputs: cs.z_in.len(), n_aux: cs.z_aux.len(), a: csr(0), b: csr(1), c: csr(2) };
+    unsafe {
+        let (mut ctx, mut pk, mut mat) = (std::ptr::null_mut(), std::ptr::null_mut(), std::ptr::null_mut());
+        let mut out = std::mem::zeroed::<zg16_proof>();
+        let mut st = zg16_ctx_create(0, &mut ctx);
+        if st == 0 { st = zg16_pk_upload(ctx, &pkv, 0, 1, &mut pk); }
+        if st == 0 { st = zg16_r1cs_upload(ctx, &rv, &mut mat); }
+        if st == 0 {
+            st = zg16_prove(ctx, pk, mat, cs.z_in.as_ptr() as *const c_void, cs.z_aux.as_ptr() as *const c_void, 0,
+                            &r as *const Fr as *const u64, &s as *const Fr as *const u64, &mut out);
+        }
+        zg16_r1cs_free(mat); zg16_pk_free(pk); zg16_ctx_destroy(ctx);
+        if st != 0 { return Err(status_to_error(st)); }
+        // coordinates are Montgomery limbs in ff_ce's own layout, so the reinterpretation below is exact
+        Ok(Proof { a: G1Affine::from_xy_unchecked(std::mem::transmute_copy(&out.a[0..4]), std::mem::transmute_copy(&out.a[4..8])),
+                   b: G2Affine::from_xy_unchecked(std::mem::transmute_copy(&out.b[0..8]), std::mem::transmute_copy(&out.b[8..16])),
+                   c: G1Affine::from_xy_unchecked(std::mem::transmute_copy(&out.c[0..4]), std::mem::transmute_copy(&out.c[4..8])) })
+    }
+}
+
+/// Drop-in for `groth16::create_random_proof` (r first, then s, both `rng.gen::<Fr>()`).
+pub fn create_random_proof<C: Circuit<Bn256>, R: Rng>(circuit: C, params: &Parameters<Bn256>, rng: &mut R) -> Result<Proof<Bn256>, SynthesisError> {
+    let r: Fr = rng.gen();
+    let s: Fr = rng.gen();
+    create_proof(circuit, params, r, s)
+}

@@ -361,3 +361,33 @@ def test_error_statuses(gpu_ctx):
     with pytest.raises(SynthesisError) as e:
         R1CS(r.n_inputs, r.n_aux, [(rp, col, co), r.mats[1], r.mats[2]]).upload(gpu_ctx)
     assert e.value.status_name == "InvalidArgument"
+
+
+def test_cpp_host_mirror_driver(gpu_ctx, tmp_path):
+    """The C++ mirror of the bellman interface (zinc_amd/host/zinc_groth16.hpp), driven like zinc-vm drives bellman."""
+    import os
+    import struct
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "bin", "host_driver")
+    assert os.path.exists(exe), "bin/host_driver missing: run __graft_entry__.build()"
+    fx = golden("prove_tiny_3.json")
+    circ, key = FixtureCircuit(fx), FixtureKey(fx)
+    params = Parameters.from_points(key)
+    pa = ProvingAssignment()
+    pa.alloc_input(1)
+    circ.synthesize(pa)          # recorded WITHOUT the input rows: the C++ side must append them itself
+    r1cs = pa.r1cs()
+    zi, za = pa.witness()
+    want = fixture_proof(fx)
+    blob = b"".join(x.tobytes() for x in (params.alpha_g1, params.beta_g1, params.beta_g2, params.delta_g1, params.delta_g2))
+    for arr in (params.h, params.l, params.a, params.b_g1, params.b_g2, zi, za):
+        blob += struct.pack("<Q", arr.shape[0]) + arr.tobytes()
+    for rp, col, co in r1cs.mats:
+        blob += struct.pack("<Q", rp.shape[0]) + rp.tobytes() + struct.pack("<Q", col.shape[0]) + col.tobytes() + co.tobytes()
+    blob += ints_to_mont([int(fx["r"], 16), int(fx["s"], 16)], R_MOD).tobytes()
+    blob += g1_to_mont([want[0]]).tobytes() + g2_to_mont([want[1]]).tobytes() + g1_to_mont([want[2]]).tobytes()
+    path = tmp_path / "case.bin"
+    path.write_bytes(blob)
+    res = subprocess.run([exe, str(path)], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr

@@ -22,7 +22,7 @@ namespace zg {
 // Kernels that per-launch timing (zg16_profile_*) distinguishes.
 enum KernelId {
   K_SPMV = 0, K_NTT_PASS, K_NTT_SCALE, K_NTT_POINTWISE, K_MSM_DIGITS, K_MSM_SCAN, K_MSM_ACC0_G1, K_MSM_ACC0_G2,
-  K_MSM_ACCN_G1, K_MSM_ACCN_G2, K_MSM_REDUCE_G1, K_MSM_REDUCE_G2, K_COUNT
+  K_MSM_ACCN_G1, K_MSM_ACCN_G2, K_MSM_REDUCE_G1, K_MSM_REDUCE_G2, K_MSM_ONES_G1, K_MSM_ONES_G2, K_COUNT
 };
 struct KernelStat {
   double ms = 0, units = 0;

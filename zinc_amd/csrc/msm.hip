@@ -476,7 +476,7 @@ static zg16_status msm_run(zg16_ctx* ctx, int scratch_slot, const MsmJob<F>* job
   if (n_ones) {
     uint32_t g = (n_ones + 256 * 16 - 1) / (256 * 16);
     if (g > max_ones_blocks) g = max_ones_blocks;
-    KernelTimer kt(ctx, is_g2 ? K_MSM_ACC0_G2 : K_MSM_ACC0_G1, (double)n_ones);
+    KernelTimer kt(ctx, is_g2 ? K_MSM_ONES_G2 : K_MSM_ONES_G1, (double)n_ones);
     k_sum_range<F><<<g, 256, 0, st>>>(jt, ent, tail[0], tail[1], part + (size_t)sh.W * red_blocks, err);
     k_sum_partials<F><<<1, 256, 0, st>>>(part + (size_t)sh.W * red_blocks, g, wsum + sh.W);
   } else {
