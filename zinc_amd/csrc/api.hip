@@ -20,6 +20,18 @@ namespace {
 
 constexpr uint32_t AUX_BIT = 0x80000000u;
 
+// Upload `count` points as window 0 of a table of `windows` windows and fill the other windows.
+template <class F>
+zg16_status upload_query(zg16_ctx* ctx, Affine<F>** dst, const void* src, size_t count, uint32_t table_c) {
+  *dst = nullptr;
+  if (!count) return ZG16_OK;
+  const size_t windows = table_c ? msm_table_windows(table_c) : 1;
+  ZG_HIP(ctx, hipMalloc((void**)dst, windows * count * sizeof(Affine<F>)));
+  ZG_HIP(ctx, hipMemcpy(*dst, src, count * sizeof(Affine<F>), hipMemcpyHostToDevice));
+  if (table_c) ZG_TRY(msm_build_table<F>(ctx, *dst, count, table_c));
+  return ZG16_OK;
+}
+
 template <class T>
 zg16_status dev_alloc_copy(zg16_ctx* ctx, T** dst, const void* src, size_t count) {
   *dst = nullptr;
@@ -99,7 +111,7 @@ zg16_status msm_entry(zg16_ctx* ctx, const uint64_t* bases, size_t n_bases, cons
   if (n_scalars) ZG_HIP(ctx, hipMemcpyAsync(d_s, scalars, s_bytes, hipMemcpyHostToDevice, ctx->stream));
   if (m_bytes) ZG_HIP(ctx, hipMemcpyAsync(d_m, map.data(), m_bytes, hipMemcpyHostToDevice, ctx->stream));
   ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  MsmJob<F> job = {d_b, d_s, density ? d_m : nullptr, n_bases};
+  MsmJob<F> job = {d_b, d_s, density ? d_m : nullptr, n_bases, 0, 0};
   XYZZ<F> res;
   ZG_TRY(run(ctx, &job, 1, &res));
   *out = to_affine(res);
@@ -173,11 +185,15 @@ zg16_status zg16_pk_upload(zg16_ctx* ctx, const zg16_pk_view* v, int shard_index
   shard_range(v->n_l, shard_index, shard_count, &pk->lo_l, &pk->hi_l);
   shard_range(v->n_a, shard_index, shard_count, &pk->lo_a, &pk->hi_a);
   shard_range(v->n_b_g1, shard_index, shard_count, &pk->lo_b, &pk->hi_b);
-  ZG_TRY(dev_alloc_copy(ctx, &pk->h, v->h + 8 * pk->lo_h, pk->hi_h - pk->lo_h));
-  ZG_TRY(dev_alloc_copy(ctx, &pk->l, v->l + 8 * pk->lo_l, pk->hi_l - pk->lo_l));
-  ZG_TRY(dev_alloc_copy(ctx, &pk->a, v->a + 8 * pk->lo_a, pk->hi_a - pk->lo_a));
-  ZG_TRY(dev_alloc_copy(ctx, &pk->b1, v->b_g1 + 8 * pk->lo_b, pk->hi_b - pk->lo_b));
-  ZG_TRY(dev_alloc_copy(ctx, &pk->b2, v->b_g2 + 16 * pk->lo_b, pk->hi_b - pk->lo_b));
+  // Window tables 2^(c*w) * P for every query: the multiexps then share one bucket set across windows.
+  size_t largest = pk->hi_h - pk->lo_h;
+  for (size_t q : {pk->hi_l - pk->lo_l, pk->hi_a - pk->lo_a, pk->hi_b - pk->lo_b}) largest = q > largest ? q : largest;
+  pk->table_c = msm_table_window(largest);
+  ZG_TRY(upload_query<Fq>(ctx, &pk->h, v->h + 8 * pk->lo_h, pk->hi_h - pk->lo_h, pk->table_c));
+  ZG_TRY(upload_query<Fq>(ctx, &pk->l, v->l + 8 * pk->lo_l, pk->hi_l - pk->lo_l, pk->table_c));
+  ZG_TRY(upload_query<Fq>(ctx, &pk->a, v->a + 8 * pk->lo_a, pk->hi_a - pk->lo_a, pk->table_c));
+  ZG_TRY(upload_query<Fq>(ctx, &pk->b1, v->b_g1 + 8 * pk->lo_b, pk->hi_b - pk->lo_b, pk->table_c));
+  ZG_TRY(upload_query<Fq2>(ctx, &pk->b2, v->b_g2 + 16 * pk->lo_b, pk->hi_b - pk->lo_b, pk->table_c));
   memcpy(&pk->alpha_g1, v->alpha_g1, 64);
   memcpy(&pk->beta_g1, v->beta_g1, 64);
   memcpy(&pk->delta_g1, v->delta_g1, 64);
@@ -320,18 +336,22 @@ zg16_status zg16_prove_partial(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1cs
     // h covers coefficients 0..m-2; this shard owns [lo_h, hi_h) clipped to that range
     const size_t hi_h = pk->hi_h < m - 1 ? pk->hi_h : m - 1;
     const size_t lo_h = pk->lo_h < hi_h ? pk->lo_h : hi_h;
-    MsmJob<Fq> jobs[2] = {{pk->h, a + lo_h, nullptr, hi_h - lo_h},
-                          {pk->l, z + r->n_in + pk->lo_l, nullptr, pk->hi_l - pk->lo_l}};
+    const uint32_t tc = pk->table_c;
+    auto stride = [&](size_t lo, size_t hi) { return tc ? hi - lo : (size_t)0; };
+    // the h table is laid out for the whole shard; skip the points below lo_h when the range was clipped
+    MsmJob<Fq> jobs[2] = {{pk->h + (lo_h - pk->lo_h), a + lo_h, nullptr, hi_h - lo_h, stride(pk->lo_h, pk->hi_h), tc},
+                          {pk->l, z + r->n_in + pk->lo_l, nullptr, pk->hi_l - pk->lo_l, stride(pk->lo_l, pk->hi_l), tc}};
     ZG_TRY(msm_g1_device(ctx, jobs, 2, &hl));
-    MsmJob<Fq> ja = {pk->a, z, r->a_map + pk->lo_a, pk->hi_a - pk->lo_a};
+    MsmJob<Fq> ja = {pk->a, z, r->a_map + pk->lo_a, pk->hi_a - pk->lo_a, stride(pk->lo_a, pk->hi_a), tc};
     ZG_TRY(msm_g1_device(ctx, &ja, 1, &qa));
-    MsmJob<Fq> jb = {pk->b1, z, r->b_map + pk->lo_b, pk->hi_b - pk->lo_b};
+    MsmJob<Fq> jb = {pk->b1, z, r->b_map + pk->lo_b, pk->hi_b - pk->lo_b, stride(pk->lo_b, pk->hi_b), tc};
     ZG_TRY(msm_g1_device(ctx, &jb, 1, &qb1));
   }
   tm.msm_g1_ms = t.stop();
   t.start();
   {
-    MsmJob<Fq2> jb = {pk->b2, z, r->b_map + pk->lo_b, pk->hi_b - pk->lo_b};
+    MsmJob<Fq2> jb = {pk->b2, z, r->b_map + pk->lo_b, pk->hi_b - pk->lo_b, pk->table_c ? pk->hi_b - pk->lo_b : (size_t)0,
+                      pk->table_c};
     ZG_TRY(msm_g2_device(ctx, &jb, 1, &qb2));
   }
   tm.msm_g2_ms = t.stop();

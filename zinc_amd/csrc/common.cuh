@@ -14,7 +14,6 @@
 namespace zg {
 
 struct NttDomain;   // ntt.hip
-struct MsmScratch;  // msm.hip
 
 }  // namespace zg
 
@@ -47,7 +46,6 @@ struct zg16_ctx {
   hipEvent_t ev[8] = {};
   std::string last_error = "";
   std::map<unsigned, zg::NttDomain*> domains;  // per log2 size
-  zg::MsmScratch* msm_scratch[2] = {nullptr, nullptr};
   // grow-only device scratch arenas, one per independent consumer
   void* scratch[6] = {};
   size_t scratch_bytes[6] = {};
@@ -167,12 +165,20 @@ struct MsmJob {
   const Fr* scalars;
   const uint32_t* index;  // optional gather map into scalars
   size_t n;
+  // Non-zero when `bases` is a window table: bases[w * table_stride + k] = 2^(table_c * w) * P_k.
+  size_t table_stride;
+  uint32_t table_c;
 };
+// Window width / count used for key tables, and the kernel that fills windows 1..W-1 of a table whose
+// window 0 (n points, stride n) is already in place.
+uint32_t msm_table_window(size_t largest_query);
+uint32_t msm_table_windows(uint32_t c);
+template <class F>
+zg16_status msm_build_table(zg16_ctx* ctx, Affine<F>* table, size_t n, uint32_t c);
 // Sum of several jobs as one multiexp; writes one XYZZ point to host memory `out`.
 zg16_status msm_g1_device(zg16_ctx* ctx, const MsmJob<Fq>* jobs, int njobs, G1XYZZ* out_host);
 zg16_status msm_g2_device(zg16_ctx* ctx, const MsmJob<Fq2>* jobs, int njobs, G2XYZZ* out_host);
 
 void ntt_free_domains(zg16_ctx* ctx);
-void msm_free_scratch(zg16_ctx* ctx);
 
 }  // namespace zg

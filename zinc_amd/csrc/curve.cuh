@@ -12,14 +12,9 @@
 #pragma once
 #include "field.cuh"
 
-// The XYZZ group operations are kept out of line on the device: a G2 addition is ~40 base-field
-// products (~15k instructions), and inlining several of them into one kernel makes hipcc's
-// register allocation take tens of minutes while the call overhead is under 2% of the work.
-#if defined(__HIPCC__)
-#define ZG_GROUP_OP __host__ __device__ __noinline__
-#else
-#define ZG_GROUP_OP inline
-#endif
+// Group operations are inlined into their callers; the field product underneath may be out of line
+// (see ZG_OUTLINE_FIELD_MUL in field.cuh).
+#define ZG_GROUP_OP ZG_HD
 
 namespace zg {
 

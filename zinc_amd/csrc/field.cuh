@@ -156,10 +156,28 @@ ZG_HD Fp<P> dbl(const Fp<P>& a) {
   return add(a, a);
 }
 
-// Montgomery product a*b*R^-1 mod p, CIOS over 32-bit digits.  Because p < 2^254 the running
+#if defined(__HIP_DEVICE_COMPILE__)
+// Montgomery product a*b*R^-1 mod p on the device: finely integrated product scanning.  Column k
+// sums a_i*b_(k-i) and m_i*p_(k-i) into a 96-bit accumulator (acc, ex), derives m_k so that the
+// column's low word vanishes, then shifts the accumulator down one word.  Every term is one
+// v_mad_u64_u32 whose addend and result are the same register pair plus one add-with-carry: 136
+// multiply-adds, 136 carry adds, three moves per column.  It is written as generated inline asm
+// (tools/gen_field_mul.py) because the C form of a column sum makes hipcc re-pair 64-bit registers
+// with two v_mov per term (gfx950 wants 64-bit VGPR operands even-aligned); modulus limbs ride in
+// scalar registers.
+template <class P>
+ZG_D Fp<P> mul_inline(const Fp<P>& a, const Fp<P>& b) {
+  Fp<P> r;
+#include "field_mul_gfx950.inc"
+  // the result is below 2p < 2^255, so nothing is left in the accumulator
+  reduce_once<P>(r.v);
+  return r;
+}
+#else
+// Montgomery product a*b*R^-1 mod p, CIOS over 32-bit digits (host).  Because p < 2^254 the running
 // value stays below 2p + epsilon, so one spare limb (t[8]) is enough.
 template <class P>
-ZG_HD Fp<P> mul(const Fp<P>& a, const Fp<P>& b) {
+inline Fp<P> mul_inline(const Fp<P>& a, const Fp<P>& b) {
   uint32_t t[9];
 #pragma unroll
   for (int i = 0; i < 9; i++) t[i] = 0;
@@ -194,6 +212,25 @@ ZG_HD Fp<P> mul(const Fp<P>& a, const Fp<P>& b) {
   for (int i = 0; i < 8; i++) r.v[i] = t[i];
   return r;
 }
+#endif
+
+// Translation units whose kernels chain dozens of products per lane (curve arithmetic) define
+// ZG_OUTLINE_FIELD_MUL: the product then is ONE out-of-line leaf function per field (operands and
+// result travel in VGPRs, ~650 instructions, few registers), every group operation is inlined around
+// calls to it, and kernels stay small enough for hipcc to allocate registers for 4 waves per SIMD.
+// Inlining the product everywhere instead makes a G2 addition ~25k instructions and out-of-line
+// group operations make every caller inherit their ~240 VGPRs (1-2 waves per SIMD).
+#if defined(__HIP_DEVICE_COMPILE__) && defined(ZG_OUTLINE_FIELD_MUL)
+template <class P>
+__device__ __noinline__ Fp<P> mul(const Fp<P> a, const Fp<P> b) {
+  return mul_inline(a, b);
+}
+#else
+template <class P>
+ZG_HD Fp<P> mul(const Fp<P>& a, const Fp<P>& b) {
+  return mul_inline(a, b);
+}
+#endif
 
 template <class P>
 ZG_HD Fp<P> sqr(const Fp<P>& a) {

@@ -2,37 +2,58 @@
 //
 // Replaces bellman_ce 0.3.0 `multiexp` (Pippenger over a CPU pool) as used by `create_proof` for
 // the h, l, a, b_g1 and b_g2 queries (reached from zinc-vm/src/core/circuit/facade.rs:153).  The
-// sum of scalar*base terms is an exact group element, so the signed-digit windows, bucket order
-// and coordinate system used here give the same affine point as upstream's unsigned windows.
+// sum of scalar*base terms is an exact group element, so the signed-digit windows, bucket order,
+// precomputed tables and coordinate system used here give the same affine point as upstream's
+// unsigned per-window buckets.
 //
-// Pipeline (all on one stream):
+// Two bucket layouts:
+//  * shared buckets (proving-key queries): the key holds 2^(c*w) * P for every window w
+//    (built once at upload by k_build_table -- 288 GB of HBM makes the W-fold copy cheap), so a
+//    digit d of window w is simply "add table[w][i] to bucket |d|".  All W windows share ONE set of
+//    2^(c-1) buckets: the bucket reduction shrinks W-fold and there is no window recombination.
+//  * per-window buckets (stand-alone multiexp on caller-supplied bases): W bucket sets, host Horner.
+//
+// Pipeline (one stream):
 //   1. k_digits<COUNT>   : Montgomery scalar -> canonical -> W signed c-bit digits; histogram
-//   2. k_scan            : exclusive scan of bucket sizes -> bucket offsets
-//   3. k_digits<SCATTER> : counting sort of (bucket, base index, sign) entries
-//   4. k_accumulate      : segmented reduction over the sorted entries.  Every lane owns a fixed
-//                          chunk of K consecutive entries whatever the bucket sizes are, so a
+//   2. k_scan_*          : exclusive scan of bucket sizes -> bucket offsets (+ largest bucket)
+//   3. k_digits<SCATTER> : counting sort of (bucket, window, base index, sign) entries
+//   4. k_accumulate<0>   : segmented reduction over the sorted entries.  Every lane owns a fixed
+//                          chunk of 64 consecutive entries whatever the bucket sizes are, so a
 //                          skewed witness (zinc witnesses are mostly 0/1 bits) cannot unbalance
-//                          the launch.  Runs that lie inside one chunk finish a bucket; runs cut
-//                          by a chunk edge go to the next level, which is reduced the same way.
-//   5. k_bucket_reduce   : sum_b (b+1)*S_b per window by segment running sums + LDS tree
-//   6. host              : Horner over the W window sums (W*c doublings)
-// Scalars equal to one (about half of a zinc witness) skip the digit path: they are appended to
-// one extra bucket through a wave-aggregated counter, which keeps them off a single hot atomic.
+//                          the launch.  A run inside one chunk finishes its bucket; a run cut by a
+//                          chunk edge leaves a partial sum in slot 2t / 2t+1.
+//   5. k_combine         : one lane per bucket adds that bucket's partials (buckets spanning at
+//                          most 32 chunks); larger buckets go through k_accumulate<level >= 1>,
+//                          the same segmented reduction applied to the partials, level by level.
+//   6. k_sum_range       : plain tree sum for scalars equal to one (about half of a zinc witness);
+//                          they reach their bucket through a wave-aggregated counter, not a digit.
+//   7. k_bucket_reduce   : sum_b (b+1)*S_b by segment running sums + LDS tree
+//   8. host              : Horner over the W window sums (per-window layout only)
+#define ZG_OUTLINE_FIELD_MUL 1
 #include "common.cuh"
 
 namespace zg {
 
-static constexpr int ACC_K = 32;      // entries per lane per level
+static constexpr int ACC_K0 = 64;     // entries per lane at level 0
+static constexpr int ACC_K = 32;      // slots per lane at levels >= 1
+static constexpr int LIGHT_SLOTS = 64;  // buckets whose partials span at most this many slots: k_combine
 static constexpr int MAX_JOBS = 4;
 static constexpr int MAX_LEVELS = 8;
 static constexpr uint32_t KEY_INVALID = 0xffffffffu;
+static constexpr uint32_t KEY_MASK = 0x00ffffffu;  // level-0 keys carry the window in the top byte
 static constexpr int RED_SEG = 8;     // buckets per lane in the window reduction
+
+// Minimum waves per SIMD requested from the register allocator for the curve kernels: a G1 lane
+// keeps ~100 live dwords (XYZZ accumulator, base, temporaries), a G2 lane twice that.
+template <class F>
+constexpr int kMinWaves = sizeof(F) > 32 ? 1 : 4;
 
 template <class F>
 struct JobTable {
   const Affine<F>* bases[MAX_JOBS];
   const Fr* scalars[MAX_JOBS];
   const uint32_t* index[MAX_JOBS];
+  uint32_t stride[MAX_JOBS];     // table stride (points per window); unused with per-window buckets
   uint32_t start[MAX_JOBS + 1];  // prefix offsets of the concatenated term list
   int njobs;
 };
@@ -41,35 +62,33 @@ struct MsmShape {
   uint32_t n;        // total terms
   uint32_t c;        // window bits
   uint32_t W;        // windows
-  uint32_t B;        // buckets per window = 2^(c-1)
-  uint32_t nb;       // W*B digit buckets; bucket nb collects the scalars equal to one
-};
-
-struct MsmScratch {
-  void* mem = nullptr;
-  size_t bytes = 0;
+  uint32_t B;        // buckets per bucket set = 2^(c-1)
+  uint32_t nb;       // digit buckets (B shared, W*B per-window); bucket nb collects the unit scalars
+  uint32_t shared;   // 1: all windows share one bucket set (table lookup), 0: one set per window
 };
 
 template <class F>
-ZG_D Fr load_scalar(const JobTable<F>& jt, uint32_t i, int* job_out, uint32_t* local_out) {
+ZG_D int find_job(const JobTable<F>& jt, uint32_t i) {
   int j = 0;
 #pragma unroll
   for (int k = 1; k < MAX_JOBS; k++)
     if (k < jt.njobs && i >= jt.start[k]) j = k;
+  return j;
+}
+
+template <class F>
+ZG_D Fr load_scalar(const JobTable<F>& jt, uint32_t i) {
+  const int j = find_job(jt, i);
   const uint32_t local = i - jt.start[j];
-  *job_out = j;
-  *local_out = local;
   const uint32_t si = jt.index[j] ? jt.index[j][local] : local;
   return jt.scalars[j][si];
 }
 
+// base of term i for window w (w = 0 when the buckets are per-window)
 template <class F>
-ZG_D Affine<F> load_base(const JobTable<F>& jt, uint32_t i) {
-  int j = 0;
-#pragma unroll
-  for (int k = 1; k < MAX_JOBS; k++)
-    if (k < jt.njobs && i >= jt.start[k]) j = k;
-  return jt.bases[j][i - jt.start[j]];
+ZG_D Affine<F> load_base(const JobTable<F>& jt, uint32_t i, uint32_t w) {
+  const int j = find_job(jt, i);
+  return jt.bases[j][(size_t)w * jt.stride[j] + (i - jt.start[j])];
 }
 
 // bits [lo, lo+c) of a 256-bit little-endian integer (c <= 24)
@@ -97,9 +116,7 @@ __global__ __launch_bounds__(256) void k_digits(JobTable<F> jt, MsmShape sh, uin
                                                 uint32_t* __restrict__ cursor,
                                                 uint32_t* __restrict__ ent, uint32_t* __restrict__ keys) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < sh.n; i += gridDim.x * blockDim.x) {
-    int job;
-    uint32_t local;
-    const Fr s = from_mont(load_scalar(jt, i, &job, &local));
+    const Fr s = from_mont(load_scalar(jt, i));
     if (s.is_zero()) continue;
     bool is_one = s.v[0] == 1;
 #pragma unroll
@@ -125,13 +142,13 @@ __global__ __launch_bounds__(256) void k_digits(JobTable<F> jt, MsmShape sh, uin
         carry = 1;
       }
       if (d) {
-        const uint32_t key = w * sh.B + d - 1;
+        const uint32_t bucket = sh.shared ? d - 1 : w * sh.B + d - 1;
         if (SCATTER) {
-          const uint32_t pos = atomicAdd(&cursor[key], 1u);
+          const uint32_t pos = atomicAdd(&cursor[bucket], 1u);
           ent[pos] = i | (neg << 31);
-          keys[pos] = key;
+          keys[pos] = sh.shared ? (bucket | (w << 24)) : bucket;
         } else {
-          atomicAdd(&hist[key], 1u);
+          atomicAdd(&hist[bucket], 1u);
         }
       }
     }
@@ -140,18 +157,22 @@ __global__ __launch_bounds__(256) void k_digits(JobTable<F> jt, MsmShape sh, uin
 
 // Exclusive scan of hist[0..count) into off[0..count] (and a copy in cursor[0..count)) in three
 // launches: per-workgroup scans of 4096 counters, a scan of the workgroup totals, a fix-up.
+// stat[0] receives the largest counter among hist[0..count-1) (the last counter is the unit-scalar
+// bucket, which has its own path).
 static constexpr uint32_t SCAN_TILE = 4096;
 
 __global__ __launch_bounds__(256) void k_scan_local(const uint32_t* __restrict__ hist, uint32_t count,
-                                                    uint32_t* __restrict__ off, uint32_t* __restrict__ tile_sum) {
+                                                    uint32_t* __restrict__ off, uint32_t* __restrict__ tile_sum,
+                                                    uint32_t* __restrict__ stat) {
   __shared__ uint32_t part[256];
   const uint32_t tid = threadIdx.x;
   const uint32_t base = blockIdx.x * SCAN_TILE + tid * 16;
-  uint32_t v[16], s = 0;
+  uint32_t v[16], s = 0, mx = 0;
 #pragma unroll
   for (int i = 0; i < 16; i++) {
     v[i] = base + i < count ? hist[base + i] : 0;
     s += v[i];
+    if (base + i + 1 < count && v[i] > mx) mx = v[i];
   }
   part[tid] = s;
   __syncthreads();
@@ -168,6 +189,7 @@ __global__ __launch_bounds__(256) void k_scan_local(const uint32_t* __restrict__
     run += v[i];
   }
   if (tid == 255) tile_sum[blockIdx.x] = part[255];
+  if (mx) atomicMax(stat, mx);
 }
 
 // One workgroup: exclusive scan of tile_sum[0..ntiles) in place; tile_sum[ntiles] = grand total.
@@ -210,7 +232,11 @@ __global__ __launch_bounds__(256) void k_scan_fixup(uint32_t* __restrict__ off, 
 
 // Slot range that bucket [s, e) of level 0 occupies at `level`.
 ZG_D void level_range(uint32_t s, uint32_t e, int level, uint32_t* rs, uint32_t* re) {
-  for (int l = 0; l < level; l++) {
+  if (level >= 1) {
+    s = 2 * (s / ACC_K0);
+    e = 2 * ((e - 1) / ACC_K0) + 2;
+  }
+  for (int l = 1; l < level; l++) {
     s = 2 * (s / ACC_K);
     e = 2 * ((e - 1) / ACC_K) + 2;
   }
@@ -218,10 +244,15 @@ ZG_D void level_range(uint32_t s, uint32_t e, int level, uint32_t* rs, uint32_t*
   *re = e;
 }
 
+// k_combine owns the buckets whose level-1 slot range is short; levels >= 1 own the rest.
+ZG_D bool bucket_is_light(uint32_t s, uint32_t e) {
+  return 2 * ((e - 1) / ACC_K0 - s / ACC_K0 + 1) <= (uint32_t)LIGHT_SLOTS;
+}
+
 // One level of the segmented reduction.  LEVEL0: entries are (base index, sign) into the job
-// table; otherwise entries are XYZZ partial sums.  Lane t owns slots [t*K, (t+1)*K).
+// table; otherwise entries are XYZZ partial sums.  Lane t owns K consecutive slots.
 template <class F, bool LEVEL0>
-__global__ __launch_bounds__(256) void k_accumulate(JobTable<F> jt, int level, uint32_t nslots,
+__global__ __launch_bounds__(256, kMinWaves<F>) void k_accumulate(JobTable<F> jt, int level, uint32_t nslots,
                                                     const uint32_t* __restrict__ keys_in,
                                                     const uint32_t* __restrict__ ent_in,
                                                     const XYZZ<F>* __restrict__ pts_in,
@@ -230,52 +261,75 @@ __global__ __launch_bounds__(256) void k_accumulate(JobTable<F> jt, int level, u
                                                     XYZZ<F>* __restrict__ pts_out,
                                                     XYZZ<F>* __restrict__ bucket_sum,
                                                     uint32_t* __restrict__ err_flag) {
+  constexpr uint32_t K = LEVEL0 ? ACC_K0 : ACC_K;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t lo = t * ACC_K;
+  const uint32_t lo = t * K;
   if (lo >= nslots) return;
-  const uint32_t hi = lo + ACC_K < nslots ? lo + ACC_K : nslots;
+  const uint32_t hi = lo + K < nslots ? lo + K : nslots;
   uint32_t cur = KEY_INVALID;
   XYZZ<F> acc = XYZZ<F>::inf();
-  bool first_run = true, head_used = false;
+  bool first_run = true, head_used = false, skip = false;
   uint32_t out_key[2] = {KEY_INVALID, KEY_INVALID};
 
-  auto flush = [&](bool last) {
-    uint32_t rs, re;
-    level_range(off[cur], off[cur + 1], level, &rs, &re);
-    if (rs >= lo && re <= lo + ACC_K) {
-      bucket_sum[cur] = acc;
-    } else {
-      // cut by a chunk edge: first run -> head slot, otherwise (necessarily the last run) tail slot
-      const int slot = (first_run && !head_used) ? 0 : 1;
-      if (slot == 0) head_used = true;
-      out_key[slot] = cur;
-      pts_out[2 * (size_t)t + slot] = acc;
+  auto flush = [&]() {
+    if (!skip) {
+      uint32_t rs, re;
+      level_range(off[cur], off[cur + 1], level, &rs, &re);
+      if (rs >= lo && re <= lo + K) {
+        bucket_sum[cur] = acc;
+      } else {
+        // cut by a chunk edge: first run -> head slot, otherwise (necessarily the last run) tail slot
+        const int slot = (first_run && !head_used) ? 0 : 1;
+        if (slot == 0) head_used = true;
+        out_key[slot] = cur;
+        pts_out[2 * (size_t)t + slot] = acc;
+      }
     }
     first_run = false;
-    (void)last;
   };
 
   for (uint32_t i = lo; i < hi; i++) {
-    const uint32_t k = keys_in[i];
-    if (k == KEY_INVALID) continue;
+    const uint32_t kw = keys_in[i];
+    if (kw == KEY_INVALID) continue;
+    const uint32_t k = LEVEL0 ? (kw & KEY_MASK) : kw;
     if (k != cur) {
-      if (cur != KEY_INVALID) flush(false);
+      if (cur != KEY_INVALID) flush();
       cur = k;
       acc = XYZZ<F>::inf();
+      if (!LEVEL0) skip = bucket_is_light(off[k], off[k + 1]);  // k_combine has summed this bucket
     }
     if (LEVEL0) {
       const uint32_t e = ent_in[i];
-      Affine<F> p = load_base(jt, e & 0x7fffffffu);
+      Affine<F> p = load_base(jt, e & 0x7fffffffu, kw >> 24);
       if (p.is_inf()) *err_flag = 1;  // identity base consumed by a non-zero scalar
       if (e >> 31) p.y = neg(p.y);
       add_mixed(acc, p);
-    } else {
+    } else if (!skip) {
       add_full(acc, pts_in[i]);
     }
   }
-  if (cur != KEY_INVALID) flush(true);
+  if (cur != KEY_INVALID) flush();
   keys_out[2 * (size_t)t] = out_key[0];
   keys_out[2 * (size_t)t + 1] = out_key[1];
+}
+
+// One lane per bucket: add the level-1 partials of a bucket that level 0 cut into a few pieces.
+template <class F>
+__global__ __launch_bounds__(256, kMinWaves<F>) void k_combine(uint32_t nb, const uint32_t* __restrict__ off,
+                                                 const uint32_t* __restrict__ keys1,
+                                                 const XYZZ<F>* __restrict__ pts1,
+                                                 XYZZ<F>* __restrict__ bucket_sum) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb) return;
+  const uint32_t s = off[b], e = off[b + 1];
+  if (e == s) return;
+  const uint32_t cf = s / ACC_K0, cl = (e - 1) / ACC_K0;
+  if (cf == cl) return;                   // finished inside one level-0 chunk
+  if (!bucket_is_light(s, e)) return;     // left to the level >= 1 reduction
+  XYZZ<F> acc = XYZZ<F>::inf();
+  for (uint32_t i = 2 * cf; i < 2 * cl + 2; i++)
+    if (keys1[i] == b) add_full(acc, pts1[i]);
+  bucket_sum[b] = acc;
 }
 
 // p * k for a small unsigned k
@@ -301,11 +355,11 @@ ZG_D void block_sum(XYZZ<F>& total, XYZZ<F>* sh /* [128] */) {
   }
 }
 
-// Window sums, stage 1: part[w][blk] = sum over this workgroup's buckets of (b+1) * S[w*B + b].
-// Grid (blocks per window, W).  A lane folds RED_SEG consecutive buckets by running sums and adds
+// Bucket-set sums, stage 1: part[w][blk] = sum over this workgroup's buckets of (b+1) * S[w*B + b].
+// Grid (blocks per set, sets).  A lane folds RED_SEG consecutive buckets by running sums and adds
 // seg_start * (segment sum); the workgroup then tree-adds through LDS.
 template <class F>
-__global__ __launch_bounds__(256) void k_bucket_reduce(const XYZZ<F>* __restrict__ bucket_sum, uint32_t B,
+__global__ __launch_bounds__(256, kMinWaves<F>) void k_bucket_reduce(const XYZZ<F>* __restrict__ bucket_sum, uint32_t B,
                                                        XYZZ<F>* __restrict__ part) {
   __shared__ XYZZ<F> sh[128];
   const uint32_t w = blockIdx.y, tid = threadIdx.x;
@@ -328,7 +382,7 @@ __global__ __launch_bounds__(256) void k_bucket_reduce(const XYZZ<F>* __restrict
 
 // out[w] = sum of part[w][0..count).  One workgroup per w.
 template <class F>
-__global__ __launch_bounds__(256) void k_sum_partials(const XYZZ<F>* __restrict__ part, uint32_t count,
+__global__ __launch_bounds__(256, kMinWaves<F>) void k_sum_partials(const XYZZ<F>* __restrict__ part, uint32_t count,
                                                       XYZZ<F>* __restrict__ out) {
   __shared__ XYZZ<F> sh[128];
   const uint32_t w = blockIdx.x, tid = threadIdx.x;
@@ -341,7 +395,7 @@ __global__ __launch_bounds__(256) void k_sum_partials(const XYZZ<F>* __restrict_
 // Plain sum of the bases named by ent[lo..hi) (the scalars equal to one): each lane adds a
 // contiguous share, the workgroup tree-adds, one partial per workgroup.
 template <class F>
-__global__ __launch_bounds__(256) void k_sum_range(JobTable<F> jt, const uint32_t* __restrict__ ent, uint32_t lo,
+__global__ __launch_bounds__(256, kMinWaves<F>) void k_sum_range(JobTable<F> jt, const uint32_t* __restrict__ ent, uint32_t lo,
                                                    uint32_t hi, XYZZ<F>* __restrict__ part,
                                                    uint32_t* __restrict__ err_flag) {
   __shared__ XYZZ<F> sh[128];
@@ -351,7 +405,7 @@ __global__ __launch_bounds__(256) void k_sum_range(JobTable<F> jt, const uint32_
   const uint32_t b = a + per < hi ? a + per : hi;
   XYZZ<F> acc = XYZZ<F>::inf();
   for (uint32_t i = a; i < b; i++) {
-    const Affine<F> p = load_base(jt, ent[i] & 0x7fffffffu);
+    const Affine<F> p = load_base(jt, ent[i] & 0x7fffffffu, 0);
     if (p.is_inf()) *err_flag = 1;
     add_mixed(acc, p);
   }
@@ -359,11 +413,24 @@ __global__ __launch_bounds__(256) void k_sum_range(JobTable<F> jt, const uint32_
   if (threadIdx.x == 0) part[blockIdx.x] = acc;
 }
 
+// table[w*stride + i] = 2^(c*w) * table[i] for w in 1..W-1 (window 0 is already in place).
+template <class F>
+__global__ __launch_bounds__(256, kMinWaves<F>) void k_build_table(Affine<F>* __restrict__ table, uint32_t n, uint32_t stride,
+                                                     uint32_t W, uint32_t c) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  XYZZ<F> acc = XYZZ<F>::from_affine(table[i]);
+  for (uint32_t w = 1; w < W; w++) {
+    for (uint32_t k = 0; k < c; k++) acc = dbl(acc);
+    table[(size_t)w * stride + i] = to_affine(acc);
+  }
+}
+
 static uint32_t pick_window(size_t n) {
   const char* e = getenv("ZG16_MSM_WINDOW");
   if (e) {
     int v = atoi(e);
-    if (v >= 2 && v <= 20) return (uint32_t)v;
+    if (v >= 2 && v <= 16) return (uint32_t)v;
   }
   unsigned lg = 0;
   while (((size_t)2 << lg) <= n) lg++;
@@ -373,6 +440,38 @@ static uint32_t pick_window(size_t n) {
   return (uint32_t)c;
 }
 
+// Table window for a key whose largest query has `largest_query` points: about 2^4..2^5 terms per
+// window per bucket keeps buckets inside k_combine's reach and the bucket reduction negligible.
+// Returns 0 when tables are switched off (ZG16_MSM_TABLE_WINDOW=0): per-window buckets are used.
+uint32_t msm_table_window(size_t largest_query) {
+  const char* e = getenv("ZG16_MSM_TABLE_WINDOW");
+  if (e) {
+    int v = atoi(e);
+    if (v == 0) return 0;
+    if (v >= 8 && v <= 20) return (uint32_t)v;
+  }
+  unsigned lg = 0;
+  while (((size_t)2 << lg) <= largest_query) lg++;
+  int c = (int)lg - 4;
+  if (c < 8) c = 8;
+  if (c > 20) c = 20;
+  return (uint32_t)c;
+}
+
+uint32_t msm_table_windows(uint32_t c) { return (255 + c - 1) / c; }
+
+template <class F>
+zg16_status msm_build_table(zg16_ctx* ctx, Affine<F>* table, size_t n, uint32_t c) {
+  if (!n) return ZG16_OK;
+  k_build_table<F><<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(table, (uint32_t)n, (uint32_t)n,
+                                                                        msm_table_windows(c), c);
+  ZG_HIP(ctx, hipGetLastError());
+  ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ZG16_OK;
+}
+template zg16_status msm_build_table<Fq>(zg16_ctx*, Affine<Fq>*, size_t, uint32_t);
+template zg16_status msm_build_table<Fq2>(zg16_ctx*, Affine<Fq2>*, size_t, uint32_t);
+
 template <class F>
 static zg16_status msm_run(zg16_ctx* ctx, int scratch_slot, const MsmJob<F>* jobs, int njobs,
                            XYZZ<F>* out_host) {
@@ -380,12 +479,17 @@ static zg16_status msm_run(zg16_ctx* ctx, int scratch_slot, const MsmJob<F>* job
   JobTable<F> jt = {};
   size_t n = 0;
   int nj = 0;
+  bool all_tables = true;
+  uint32_t table_c = 0;
   for (int j = 0; j < njobs; j++) {
     if (!jobs[j].n) continue;
     jt.bases[nj] = jobs[j].bases;
     jt.scalars[nj] = jobs[j].scalars;
     jt.index[nj] = jobs[j].index;
+    jt.stride[nj] = (uint32_t)jobs[j].table_stride;
     jt.start[nj] = (uint32_t)n;
+    if (!jobs[j].table_stride || (table_c && jobs[j].table_c != table_c)) all_tables = false;
+    table_c = jobs[j].table_c;
     n += jobs[j].n;
     nj++;
   }
@@ -397,10 +501,14 @@ static zg16_status msm_run(zg16_ctx* ctx, int scratch_slot, const MsmJob<F>* job
 
   MsmShape sh;
   sh.n = (uint32_t)n;
-  sh.c = pick_window(n);
+  sh.shared = all_tables ? 1 : 0;
+  sh.c = sh.shared ? table_c : pick_window(n);
   sh.W = (255 + sh.c - 1) / sh.c;
   sh.B = 1u << (sh.c - 1);
-  sh.nb = sh.W * sh.B;
+  sh.nb = sh.shared ? sh.B : sh.W * sh.B;
+  if (!sh.shared)
+    for (int j = 0; j < nj; j++) jt.stride[j] = 0;
+  const uint32_t nsets = sh.shared ? 1 : sh.W;
   const size_t max_entries = (size_t)sh.W * n;
   if (max_entries >= 0xfffffff0ull) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "multiexp too large for 32-bit entry offsets");
 
@@ -409,7 +517,8 @@ static zg16_status msm_run(zg16_ctx* ctx, int scratch_slot, const MsmJob<F>* job
   int nlevels = 0;
   lvl[0] = max_entries;
   while (true) {
-    const size_t chunks = (lvl[nlevels] + ACC_K - 1) / ACC_K;
+    const size_t k = nlevels == 0 ? ACC_K0 : ACC_K;
+    const size_t chunks = (lvl[nlevels] + k - 1) / k;
     lvl[nlevels + 1] = 2 * chunks;
     nlevels++;
     if (chunks <= 1) break;
@@ -421,7 +530,7 @@ static zg16_status msm_run(zg16_ctx* ctx, int scratch_slot, const MsmJob<F>* job
   const size_t o_hist = o;   o += align((sh.nb + 1) * 4);
   const size_t o_off = o;    o += align((sh.nb + 2) * 4);
   const size_t o_cur = o;    o += align((sh.nb + 1) * 4);
-  const size_t o_err = o;    o += 256;
+  const size_t o_err = o;    o += 256;  // [0] identity-base flag, [1] largest digit bucket
   const size_t o_ent = o;    o += align(max_entries * 4);
   const size_t o_key0 = o;   o += align(max_entries * 4);
   size_t o_keys[MAX_LEVELS + 1], o_pts[MAX_LEVELS + 1];
@@ -430,12 +539,12 @@ static zg16_status msm_run(zg16_ctx* ctx, int scratch_slot, const MsmJob<F>* job
     o_pts[l] = o;  o += align(lvl[l] * sizeof(XYZZ<F>));
   }
   const size_t o_bsum = o;   o += align((size_t)(sh.nb + 1) * sizeof(XYZZ<F>));
-  const size_t o_wsum = o;   o += align((size_t)(sh.W + 1) * sizeof(XYZZ<F>));
+  const size_t o_wsum = o;   o += align((size_t)(nsets + 1) * sizeof(XYZZ<F>));
   const uint32_t ntiles = (sh.nb + 1 + SCAN_TILE - 1) / SCAN_TILE;
   const uint32_t red_blocks = (sh.B + 256 * RED_SEG - 1) / (256 * RED_SEG);
   const uint32_t max_ones_blocks = 1024;
   const size_t o_tiles = o;  o += align((size_t)(ntiles + 1) * 4);
-  const size_t o_part = o;   o += align((size_t)(sh.W * red_blocks + max_ones_blocks) * sizeof(XYZZ<F>));
+  const size_t o_part = o;   o += align((size_t)(nsets * red_blocks + max_ones_blocks) * sizeof(XYZZ<F>));
   char* base;
   ZG_TRY(scratch_get(ctx, scratch_slot, o, (void**)&base));
   uint32_t* hist = (uint32_t*)(base + o_hist);
@@ -460,7 +569,7 @@ static zg16_status msm_run(zg16_ctx* ctx, int scratch_slot, const MsmJob<F>* job
   }
   {
     KernelTimer kt(ctx, K_MSM_SCAN, (double)sh.nb);
-    k_scan_local<<<ntiles, 256, 0, st>>>(hist, sh.nb + 1, off, tiles);
+    k_scan_local<<<ntiles, 256, 0, st>>>(hist, sh.nb + 1, off, tiles, err + 1);
     k_scan_tiles<<<1, 1024, 0, st>>>(tiles, ntiles);
     k_scan_fixup<<<(sh.nb + 2 + 255) / 256, 256, 0, st>>>(off, cursor, sh.nb + 1, tiles, ntiles);
   }
@@ -468,8 +577,10 @@ static zg16_status msm_run(zg16_ctx* ctx, int scratch_slot, const MsmJob<F>* job
     KernelTimer kt(ctx, K_MSM_DIGITS, (double)n);
     k_digits<F, true><<<dgrid, 256, 0, st>>>(jt, sh, hist, cursor, ent, key0);
   }
-  uint32_t tail[2] = {0, 0};  // start of the ones range, total entries
+  uint32_t tail[2] = {0, 0};  // start of the unit-scalar range, total entries
+  uint32_t max_bucket = 0;
   ZG_HIP(ctx, hipMemcpyAsync(tail, off + sh.nb, 8, hipMemcpyDeviceToHost, st));
+  ZG_HIP(ctx, hipMemcpyAsync(&max_bucket, err + 1, 4, hipMemcpyDeviceToHost, st));
   ZG_HIP(ctx, hipStreamSynchronize(st));
   // the scalars equal to one: a plain tree sum, kept out of the segmented reduction
   const uint32_t n_ones = tail[1] - tail[0];
@@ -477,46 +588,56 @@ static zg16_status msm_run(zg16_ctx* ctx, int scratch_slot, const MsmJob<F>* job
     uint32_t g = (n_ones + 256 * 16 - 1) / (256 * 16);
     if (g > max_ones_blocks) g = max_ones_blocks;
     KernelTimer kt(ctx, is_g2 ? K_MSM_ONES_G2 : K_MSM_ONES_G1, (double)n_ones);
-    k_sum_range<F><<<g, 256, 0, st>>>(jt, ent, tail[0], tail[1], part + (size_t)sh.W * red_blocks, err);
-    k_sum_partials<F><<<1, 256, 0, st>>>(part + (size_t)sh.W * red_blocks, g, wsum + sh.W);
+    k_sum_range<F><<<g, 256, 0, st>>>(jt, ent, tail[0], tail[1], part + (size_t)nsets * red_blocks, err);
+    k_sum_partials<F><<<1, 256, 0, st>>>(part + (size_t)nsets * red_blocks, g, wsum + nsets);
   } else {
-    ZG_HIP(ctx, hipMemsetAsync(wsum + sh.W, 0, sizeof(XYZZ<F>), st));
+    ZG_HIP(ctx, hipMemsetAsync(wsum + nsets, 0, sizeof(XYZZ<F>), st));
   }
-  // levels, sized by the actual entry count of the digit buckets
-  size_t slots = tail[0];
-  for (int l = 0; slots > 0; l++) {
-    const size_t chunks = (slots + ACC_K - 1) / ACC_K;
-    const unsigned grid = (unsigned)((chunks + 255) / 256);
-    KernelTimer kt(ctx, l == 0 ? (is_g2 ? K_MSM_ACC0_G2 : K_MSM_ACC0_G1) : (is_g2 ? K_MSM_ACCN_G2 : K_MSM_ACCN_G1),
-                   (double)slots);
-    if (l == 0)
-      k_accumulate<F, true><<<grid, 256, 0, st>>>(jt, 0, (uint32_t)slots, key0, ent, nullptr, off,
-                                                  (uint32_t*)(base + o_keys[1]), (XYZZ<F>*)(base + o_pts[1]), bsum, err);
-    else
-      k_accumulate<F, false><<<grid, 256, 0, st>>>(jt, l, (uint32_t)slots, (uint32_t*)(base + o_keys[l]), nullptr,
-                                                   (XYZZ<F>*)(base + o_pts[l]), off, (uint32_t*)(base + o_keys[l + 1]),
-                                                   (XYZZ<F>*)(base + o_pts[l + 1]), bsum, err);
-    if (chunks <= 1) break;
-    slots = 2 * chunks;
+  const size_t entries = tail[0];
+  if (entries) {
+    const size_t chunks0 = (entries + ACC_K0 - 1) / ACC_K0;
+    {
+      KernelTimer kt(ctx, is_g2 ? K_MSM_ACC0_G2 : K_MSM_ACC0_G1, (double)entries);
+      k_accumulate<F, true><<<(unsigned)((chunks0 + 255) / 256), 256, 0, st>>>(
+          jt, 0, (uint32_t)entries, key0, ent, nullptr, off, (uint32_t*)(base + o_keys[1]), (XYZZ<F>*)(base + o_pts[1]),
+          bsum, err);
+    }
+    if (chunks0 > 1) {
+      KernelTimer kt(ctx, is_g2 ? K_MSM_ACCN_G2 : K_MSM_ACCN_G1, (double)(2 * chunks0));
+      k_combine<F><<<(sh.nb + 255) / 256, 256, 0, st>>>(sh.nb, off, (const uint32_t*)(base + o_keys[1]),
+                                                        (const XYZZ<F>*)(base + o_pts[1]), bsum);
+      // Buckets too large for k_combine exist only if some bucket spans more than LIGHT_SLOTS/2 chunks.
+      const bool heavy = (size_t)max_bucket > (size_t)(LIGHT_SLOTS / 2 - 1) * ACC_K0;
+      size_t slots = 2 * chunks0;
+      for (int l = 1; heavy; l++) {
+        const size_t chunks = (slots + ACC_K - 1) / ACC_K;
+        k_accumulate<F, false><<<(unsigned)((chunks + 255) / 256), 256, 0, st>>>(
+            jt, l, (uint32_t)slots, (uint32_t*)(base + o_keys[l]), nullptr, (XYZZ<F>*)(base + o_pts[l]), off,
+            (uint32_t*)(base + o_keys[l + 1]), (XYZZ<F>*)(base + o_pts[l + 1]), bsum, err);
+        if (chunks <= 1) break;
+        slots = 2 * chunks;
+      }
+    }
   }
   {
     KernelTimer kt(ctx, is_g2 ? K_MSM_REDUCE_G2 : K_MSM_REDUCE_G1, (double)sh.nb);
-    k_bucket_reduce<F><<<dim3(red_blocks, sh.W), 256, 0, st>>>(bsum, sh.B, part);
-    k_sum_partials<F><<<sh.W, 256, 0, st>>>(part, red_blocks, wsum);
+    k_bucket_reduce<F><<<dim3(red_blocks, nsets), 256, 0, st>>>(bsum, sh.B, part);
+    k_sum_partials<F><<<nsets, 256, 0, st>>>(part, red_blocks, wsum);
   }
   ZG_HIP(ctx, hipGetLastError());
-  std::vector<XYZZ<F>> hw(sh.W + 1);
+  std::vector<XYZZ<F>> hw(nsets + 1);
   uint32_t herr = 0;
-  ZG_HIP(ctx, hipMemcpyAsync(hw.data(), wsum, (sh.W + 1) * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
+  ZG_HIP(ctx, hipMemcpyAsync(hw.data(), wsum, (nsets + 1) * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
   ZG_HIP(ctx, hipMemcpyAsync(&herr, err, 4, hipMemcpyDeviceToHost, st));
   ZG_HIP(ctx, hipStreamSynchronize(st));
   if (herr) return fail(ctx, ZG16_ERR_UNEXPECTED_IDENTITY, "multiexp consumed a base at infinity");
   XYZZ<F> total = XYZZ<F>::inf();
-  for (int w = (int)sh.W - 1; w >= 0; w--) {
-    for (uint32_t k = 0; k < sh.c; k++) total = dbl(total);
+  for (int w = (int)nsets - 1; w >= 0; w--) {
+    if (!sh.shared)
+      for (uint32_t k = 0; k < sh.c; k++) total = dbl(total);
     add_full(total, hw[w]);
   }
-  add_full(total, hw[sh.W]);  // the scalars equal to one
+  add_full(total, hw[nsets]);  // the scalars equal to one
   *out_host = total;
   return ZG16_OK;
 }
@@ -527,7 +648,5 @@ zg16_status msm_g1_device(zg16_ctx* ctx, const MsmJob<Fq>* jobs, int njobs, G1XY
 zg16_status msm_g2_device(zg16_ctx* ctx, const MsmJob<Fq2>* jobs, int njobs, G2XYZZ* out_host) {
   return msm_run<Fq2>(ctx, 2, jobs, njobs, out_host);
 }
-
-void msm_free_scratch(zg16_ctx*) {}
 
 }  // namespace zg

@@ -2,6 +2,7 @@
 // them (edge cases included) against golden vectors through the C ABI.  Not used while proving.
 #include <string.h>
 
+#define ZG_OUTLINE_FIELD_MUL 1
 #include "common.cuh"
 
 namespace zg {

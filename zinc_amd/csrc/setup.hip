@@ -9,6 +9,7 @@
 // mixed additions and converts its own result to affine.
 #include <string.h>
 
+#define ZG_OUTLINE_FIELD_MUL 1
 #include "common.cuh"
 
 namespace zg {
