@@ -43,12 +43,14 @@ struct zg16_ctx {
   hipStream_t stream = nullptr;      // stream all kernels are issued on
   hipStream_t own_stream = nullptr;  // created by the context
   hipStream_t aux_stream = nullptr;  // second stream for overlapping independent stages
+  hipStream_t msm_stream[4] = {};    // one per concurrent multiexp of a proof
+  void* pinned = nullptr;            // page-locked host memory for small asynchronous read-backs
   hipEvent_t ev[8] = {};
   std::string last_error = "";
   std::map<unsigned, zg::NttDomain*> domains;  // per log2 size
   // grow-only device scratch arenas, one per independent consumer
-  void* scratch[6] = {};
-  size_t scratch_bytes[6] = {};
+  void* scratch[10] = {};
+  size_t scratch_bytes[10] = {};
   zg16_timings timings = {};
 };
 
@@ -101,18 +103,20 @@ struct KernelTimer {
   zg16_ctx* ctx;
   PendingTiming p;
   bool on;
-  KernelTimer(zg16_ctx* c, int id, double units) : ctx(c), on(c->profile) {
+  hipStream_t st;
+  KernelTimer(zg16_ctx* c, int id, double units, hipStream_t stream = nullptr)
+      : ctx(c), on(c->profile), st(stream ? stream : c->stream) {
     if (!on) return;
     p.id = id;
     p.units = units;
     p.a = grab();
     p.b = grab();
     if (!p.a || !p.b) { on = false; return; }
-    (void)hipEventRecord(p.a, ctx->stream);
+    (void)hipEventRecord(p.a, st);
   }
   ~KernelTimer() {
     if (!on) return;
-    (void)hipEventRecord(p.b, ctx->stream);
+    (void)hipEventRecord(p.b, st);
     ctx->pending.push_back(p);
   }
   hipEvent_t grab() {
@@ -178,6 +182,22 @@ zg16_status msm_build_table(zg16_ctx* ctx, Affine<F>* table, size_t n, uint32_t 
 // Sum of several jobs as one multiexp; writes one XYZZ point to host memory `out`.
 zg16_status msm_g1_device(zg16_ctx* ctx, const MsmJob<Fq>* jobs, int njobs, G1XYZZ* out_host);
 zg16_status msm_g2_device(zg16_ctx* ctx, const MsmJob<Fq2>* jobs, int njobs, G2XYZZ* out_host);
+
+// The same multiexp in three stages so that several can be in flight on different streams:
+// msm_sort launches digits / scan / counting sort and an asynchronous read-back of the entry
+// counts; after that stream is idle msm_reduce launches accumulation and reduction; after it is
+// idle again msm_finish does the host part.  `pinned` is >= 16 KiB of page-locked host memory.
+struct MsmPlanBase {
+  virtual ~MsmPlanBase() {}
+};
+template <class F>
+zg16_status msm_sort(zg16_ctx* ctx, hipStream_t st, int scratch_slot, void* pinned, const MsmJob<F>* jobs, int njobs,
+                     MsmPlanBase** plan);
+template <class F>
+zg16_status msm_reduce(zg16_ctx* ctx, MsmPlanBase* plan);
+template <class F>
+zg16_status msm_finish(zg16_ctx* ctx, MsmPlanBase* plan, XYZZ<F>* out_host);
+static constexpr size_t MSM_PINNED_BYTES = 16384;
 
 void ntt_free_domains(zg16_ctx* ctx);
 

@@ -17,14 +17,14 @@
 //   1. k_digits<COUNT>   : Montgomery scalar -> canonical -> W signed c-bit digits; histogram
 //   2. k_scan_*          : exclusive scan of bucket sizes -> bucket offsets (+ largest bucket)
 //   3. k_digits<SCATTER> : counting sort of (bucket, window, base index, sign) entries
-//   4. k_accumulate<0>   : segmented reduction over the sorted entries.  Every lane owns a fixed
+//   4. k_accumulate      : segmented reduction over the sorted entries.  Every lane owns a fixed
 //                          chunk of 64 consecutive entries whatever the bucket sizes are, so a
 //                          skewed witness (zinc witnesses are mostly 0/1 bits) cannot unbalance
 //                          the launch.  A run inside one chunk finishes its bucket; a run cut by a
 //                          chunk edge leaves a partial sum in slot 2t / 2t+1.
-//   5. k_combine         : one lane per bucket adds that bucket's partials (buckets spanning at
-//                          most 32 chunks); larger buckets go through k_accumulate<level >= 1>,
-//                          the same segmented reduction applied to the partials, level by level.
+//   5. k_combine         : eight lanes per bucket add that bucket's partials (buckets spanning at
+//                          most 32 chunks) and fold by shuffles; larger buckets get one workgroup
+//                          each in k_heavy.
 //   6. k_sum_range       : plain tree sum for scalars equal to one (about half of a zinc witness);
 //                          they reach their bucket through a wave-aggregated counter, not a digit.
 //   7. k_bucket_reduce   : sum_b (b+1)*S_b by segment running sums + LDS tree
@@ -35,10 +35,8 @@
 namespace zg {
 
 static constexpr int ACC_K0 = 64;     // entries per lane at level 0
-static constexpr int ACC_K = 32;      // slots per lane at levels >= 1
 static constexpr int LIGHT_SLOTS = 64;  // buckets whose partials span at most this many slots: k_combine
 static constexpr int MAX_JOBS = 4;
-static constexpr int MAX_LEVELS = 8;
 static constexpr uint32_t KEY_INVALID = 0xffffffffu;
 static constexpr uint32_t KEY_MASK = 0x00ffffffu;  // level-0 keys carry the window in the top byte
 static constexpr int RED_SEG = 8;     // buckets per lane in the window reduction
@@ -230,107 +228,123 @@ __global__ __launch_bounds__(256) void k_scan_fixup(uint32_t* __restrict__ off, 
   }
 }
 
-// Slot range that bucket [s, e) of level 0 occupies at `level`.
-ZG_D void level_range(uint32_t s, uint32_t e, int level, uint32_t* rs, uint32_t* re) {
-  if (level >= 1) {
-    s = 2 * (s / ACC_K0);
-    e = 2 * ((e - 1) / ACC_K0) + 2;
-  }
-  for (int l = 1; l < level; l++) {
-    s = 2 * (s / ACC_K);
-    e = 2 * ((e - 1) / ACC_K) + 2;
-  }
-  *rs = s;
-  *re = e;
-}
-
-// k_combine owns the buckets whose level-1 slot range is short; levels >= 1 own the rest.
+// k_combine owns the buckets whose partial slots span at most LIGHT_SLOTS; k_heavy owns the rest.
 ZG_D bool bucket_is_light(uint32_t s, uint32_t e) {
   return 2 * ((e - 1) / ACC_K0 - s / ACC_K0 + 1) <= (uint32_t)LIGHT_SLOTS;
 }
 
-// One level of the segmented reduction.  LEVEL0: entries are (base index, sign) into the job
-// table; otherwise entries are XYZZ partial sums.  Lane t owns K consecutive slots.
-template <class F, bool LEVEL0>
-__global__ __launch_bounds__(256, kMinWaves<F>) void k_accumulate(JobTable<F> jt, int level, uint32_t nslots,
-                                                    const uint32_t* __restrict__ keys_in,
-                                                    const uint32_t* __restrict__ ent_in,
-                                                    const XYZZ<F>* __restrict__ pts_in,
-                                                    const uint32_t* __restrict__ off,
-                                                    uint32_t* __restrict__ keys_out,
-                                                    XYZZ<F>* __restrict__ pts_out,
-                                                    XYZZ<F>* __restrict__ bucket_sum,
-                                                    uint32_t* __restrict__ err_flag) {
-  constexpr uint32_t K = LEVEL0 ? ACC_K0 : ACC_K;
+// Level 0 of the segmented reduction: lane t owns sorted entries [64t, 64t+64) whatever the bucket
+// sizes are.  A run that lies inside the chunk finishes its bucket; a run cut by a chunk edge
+// leaves a partial sum in slot 2t (first run) or 2t+1 (last run) for k_combine / k_heavy.
+template <class F>
+__global__ __launch_bounds__(256, kMinWaves<F>) void k_accumulate(JobTable<F> jt, uint32_t nslots,
+                                                                  const uint32_t* __restrict__ keys_in,
+                                                                  const uint32_t* __restrict__ ent_in,
+                                                                  const uint32_t* __restrict__ off,
+                                                                  uint32_t* __restrict__ keys_out,
+                                                                  XYZZ<F>* __restrict__ pts_out,
+                                                                  XYZZ<F>* __restrict__ bucket_sum,
+                                                                  uint32_t* __restrict__ err_flag) {
+  constexpr uint32_t K = ACC_K0;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t lo = t * K;
   if (lo >= nslots) return;
   const uint32_t hi = lo + K < nslots ? lo + K : nslots;
   uint32_t cur = KEY_INVALID;
   XYZZ<F> acc = XYZZ<F>::inf();
-  bool first_run = true, head_used = false, skip = false;
+  bool first_run = true;
   uint32_t out_key[2] = {KEY_INVALID, KEY_INVALID};
 
   auto flush = [&]() {
-    if (!skip) {
-      uint32_t rs, re;
-      level_range(off[cur], off[cur + 1], level, &rs, &re);
-      if (rs >= lo && re <= lo + K) {
-        bucket_sum[cur] = acc;
-      } else {
-        // cut by a chunk edge: first run -> head slot, otherwise (necessarily the last run) tail slot
-        const int slot = (first_run && !head_used) ? 0 : 1;
-        if (slot == 0) head_used = true;
-        out_key[slot] = cur;
-        pts_out[2 * (size_t)t + slot] = acc;
-      }
+    if (off[cur] >= lo && off[cur + 1] <= lo + K) {
+      bucket_sum[cur] = acc;
+    } else {
+      const int slot = first_run ? 0 : 1;  // a cut run is the first or (otherwise) the last of its chunk
+      out_key[slot] = cur;
+      pts_out[2 * (size_t)t + slot] = acc;
     }
     first_run = false;
   };
 
   for (uint32_t i = lo; i < hi; i++) {
     const uint32_t kw = keys_in[i];
-    if (kw == KEY_INVALID) continue;
-    const uint32_t k = LEVEL0 ? (kw & KEY_MASK) : kw;
+    const uint32_t k = kw & KEY_MASK;
     if (k != cur) {
       if (cur != KEY_INVALID) flush();
       cur = k;
       acc = XYZZ<F>::inf();
-      if (!LEVEL0) skip = bucket_is_light(off[k], off[k + 1]);  // k_combine has summed this bucket
     }
-    if (LEVEL0) {
-      const uint32_t e = ent_in[i];
-      Affine<F> p = load_base(jt, e & 0x7fffffffu, kw >> 24);
-      if (p.is_inf()) *err_flag = 1;  // identity base consumed by a non-zero scalar
-      if (e >> 31) p.y = neg(p.y);
-      add_mixed(acc, p);
-    } else if (!skip) {
-      add_full(acc, pts_in[i]);
-    }
+    const uint32_t e = ent_in[i];
+    Affine<F> p = load_base(jt, e & 0x7fffffffu, kw >> 24);
+    if (p.is_inf()) *err_flag = 1;  // identity base consumed by a non-zero scalar
+    if (e >> 31) p.y = neg(p.y);
+    add_mixed(acc, p);
   }
   if (cur != KEY_INVALID) flush();
   keys_out[2 * (size_t)t] = out_key[0];
   keys_out[2 * (size_t)t + 1] = out_key[1];
 }
 
-// One lane per bucket: add the level-1 partials of a bucket that level 0 cut into a few pieces.
+template <class F>
+ZG_D XYZZ<F> shfl_down_point(const XYZZ<F>& p, int d) {
+  XYZZ<F> o;
+  const uint32_t* src = (const uint32_t*)&p;
+  uint32_t* dst = (uint32_t*)&o;
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(XYZZ<F>) / 4); i++) dst[i] = __shfl_down(src[i], d);
+  return o;
+}
+
+// COMBINE_LANES lanes per bucket add the partial sums level 0 left for a bucket it cut into a few
+// pieces, then fold across the lanes by shuffles.  Buckets spanning more than LIGHT_SLOTS slots are
+// appended to heavy_list for k_heavy.
+static constexpr int COMBINE_LANES = 8;
 template <class F>
 __global__ __launch_bounds__(256, kMinWaves<F>) void k_combine(uint32_t nb, const uint32_t* __restrict__ off,
-                                                 const uint32_t* __restrict__ keys1,
-                                                 const XYZZ<F>* __restrict__ pts1,
-                                                 XYZZ<F>* __restrict__ bucket_sum) {
-  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= nb) return;
-  const uint32_t s = off[b], e = off[b + 1];
-  if (e == s) return;
-  const uint32_t cf = s / ACC_K0, cl = (e - 1) / ACC_K0;
-  if (cf == cl) return;                   // finished inside one level-0 chunk
-  if (!bucket_is_light(s, e)) return;     // left to the level >= 1 reduction
+                                                                 const uint32_t* __restrict__ keys1,
+                                                                 const XYZZ<F>* __restrict__ pts1,
+                                                                 XYZZ<F>* __restrict__ bucket_sum,
+                                                                 uint32_t* __restrict__ heavy_count,
+                                                                 uint32_t* __restrict__ heavy_list) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t b = t / COMBINE_LANES, sub = t % COMBINE_LANES;
+  uint32_t lo = 0, hi = 0;  // slot range this bucket's lanes share; empty when there is nothing to add
+  if (b < nb) {
+    const uint32_t s = off[b], e = off[b + 1];
+    if (e > s) {
+      const uint32_t cf = s / ACC_K0, cl = (e - 1) / ACC_K0;
+      if (cf != cl) {  // otherwise level 0 finished it inside one chunk
+        if (bucket_is_light(s, e)) {
+          lo = 2 * cf;
+          hi = 2 * cl + 2;
+        } else if (sub == 0) {
+          heavy_list[atomicAdd(heavy_count, 1u)] = b;
+        }
+      }
+    }
+  }
   XYZZ<F> acc = XYZZ<F>::inf();
-  for (uint32_t i = 2 * cf; i < 2 * cl + 2; i++)
+  for (uint32_t i = lo + sub; i < hi; i += COMBINE_LANES)
     if (keys1[i] == b) add_full(acc, pts1[i]);
-  bucket_sum[b] = acc;
+  // the lanes of one bucket are adjacent in the wave and all of them reach this point
+  if (__ballot(hi > lo) != 0) {
+    for (int d = COMBINE_LANES / 2; d >= 1; d >>= 1) {
+      const XYZZ<F> o = shfl_down_point(acc, d);
+      if (sub + d < COMBINE_LANES) add_full(acc, o);
+    }
+  }
+  if (hi > lo && sub == 0) bucket_sum[b] = acc;
 }
+
+// One workgroup per heavy bucket (grid-stride over heavy_list): lanes stride over the bucket's
+// partial slots, then the workgroup tree-adds through LDS.
+template <class F>
+__global__ __launch_bounds__(256, kMinWaves<F>) void k_heavy(const uint32_t* __restrict__ heavy_count,
+                                                               const uint32_t* __restrict__ heavy_list,
+                                                               const uint32_t* __restrict__ off,
+                                                               const uint32_t* __restrict__ keys1,
+                                                               const XYZZ<F>* __restrict__ pts1,
+                                                               XYZZ<F>* __restrict__ bucket_sum);
 
 // p * k for a small unsigned k
 template <class F>
@@ -352,6 +366,27 @@ ZG_D void block_sum(XYZZ<F>& total, XYZZ<F>* sh /* [128] */) {
     __syncthreads();
     if (tid < stride) add_full(total, sh[tid]);
     __syncthreads();
+  }
+}
+
+template <class F>
+__global__ __launch_bounds__(256, kMinWaves<F>) void k_heavy(const uint32_t* __restrict__ heavy_count,
+                                                               const uint32_t* __restrict__ heavy_list,
+                                                               const uint32_t* __restrict__ off,
+                                                               const uint32_t* __restrict__ keys1,
+                                                               const XYZZ<F>* __restrict__ pts1,
+                                                               XYZZ<F>* __restrict__ bucket_sum) {
+  __shared__ XYZZ<F> sh[128];
+  const uint32_t n = *heavy_count;
+  for (uint32_t h = blockIdx.x; h < n; h += gridDim.x) {
+    const uint32_t b = heavy_list[h];
+    const uint32_t s = off[b], e = off[b + 1];
+    const uint32_t lo = 2 * (s / ACC_K0), hi = 2 * ((e - 1) / ACC_K0) + 2;
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 256)
+      if (keys1[i] == b) add_full(acc, pts1[i]);
+    block_sum(acc, sh);
+    if (threadIdx.x == 0) bucket_sum[b] = acc;
   }
 }
 
@@ -512,32 +547,19 @@ static zg16_status msm_run(zg16_ctx* ctx, int scratch_slot, const MsmJob<F>* job
   const size_t max_entries = (size_t)sh.W * n;
   if (max_entries >= 0xfffffff0ull) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "multiexp too large for 32-bit entry offsets");
 
-  // level sizes (slots) for the worst case
-  size_t lvl[MAX_LEVELS + 1];
-  int nlevels = 0;
-  lvl[0] = max_entries;
-  while (true) {
-    const size_t k = nlevels == 0 ? ACC_K0 : ACC_K;
-    const size_t chunks = (lvl[nlevels] + k - 1) / k;
-    lvl[nlevels + 1] = 2 * chunks;
-    nlevels++;
-    if (chunks <= 1) break;
-    if (nlevels >= MAX_LEVELS) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "multiexp level overflow");
-  }
   // scratch layout
   auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
   size_t o = 0;
   const size_t o_hist = o;   o += align((sh.nb + 1) * 4);
   const size_t o_off = o;    o += align((sh.nb + 2) * 4);
   const size_t o_cur = o;    o += align((sh.nb + 1) * 4);
-  const size_t o_err = o;    o += 256;  // [0] identity-base flag, [1] largest digit bucket
+  const size_t o_err = o;    o += 256;  // [0] identity-base flag, [1] largest digit bucket, [2] heavy buckets
   const size_t o_ent = o;    o += align(max_entries * 4);
   const size_t o_key0 = o;   o += align(max_entries * 4);
-  size_t o_keys[MAX_LEVELS + 1], o_pts[MAX_LEVELS + 1];
-  for (int l = 1; l <= nlevels; l++) {
-    o_keys[l] = o; o += align(lvl[l] * 4);
-    o_pts[l] = o;  o += align(lvl[l] * sizeof(XYZZ<F>));
-  }
+  const size_t max_slots = 2 * ((max_entries + ACC_K0 - 1) / ACC_K0);
+  const size_t o_keys1 = o;  o += align(max_slots * 4);
+  const size_t o_pts1 = o;   o += align(max_slots * sizeof(XYZZ<F>));
+  const size_t o_heavy = o;  o += align((size_t)sh.nb * 4);
   const size_t o_bsum = o;   o += align((size_t)(sh.nb + 1) * sizeof(XYZZ<F>));
   const size_t o_wsum = o;   o += align((size_t)(nsets + 1) * sizeof(XYZZ<F>));
   const uint32_t ntiles = (sh.nb + 1 + SCAN_TILE - 1) / SCAN_TILE;
@@ -596,27 +618,20 @@ static zg16_status msm_run(zg16_ctx* ctx, int scratch_slot, const MsmJob<F>* job
   const size_t entries = tail[0];
   if (entries) {
     const size_t chunks0 = (entries + ACC_K0 - 1) / ACC_K0;
+    uint32_t* keys1 = (uint32_t*)(base + o_keys1);
+    XYZZ<F>* pts1 = (XYZZ<F>*)(base + o_pts1);
     {
       KernelTimer kt(ctx, is_g2 ? K_MSM_ACC0_G2 : K_MSM_ACC0_G1, (double)entries);
-      k_accumulate<F, true><<<(unsigned)((chunks0 + 255) / 256), 256, 0, st>>>(
-          jt, 0, (uint32_t)entries, key0, ent, nullptr, off, (uint32_t*)(base + o_keys[1]), (XYZZ<F>*)(base + o_pts[1]),
-          bsum, err);
+      k_accumulate<F><<<(unsigned)((chunks0 + 255) / 256), 256, 0, st>>>(jt, (uint32_t)entries, key0, ent, off, keys1,
+                                                                         pts1, bsum, err);
     }
     if (chunks0 > 1) {
       KernelTimer kt(ctx, is_g2 ? K_MSM_ACCN_G2 : K_MSM_ACCN_G1, (double)(2 * chunks0));
-      k_combine<F><<<(sh.nb + 255) / 256, 256, 0, st>>>(sh.nb, off, (const uint32_t*)(base + o_keys[1]),
-                                                        (const XYZZ<F>*)(base + o_pts[1]), bsum);
+      k_combine<F><<<(unsigned)(((size_t)sh.nb * COMBINE_LANES + 255) / 256), 256, 0, st>>>(
+          sh.nb, off, keys1, pts1, bsum, err + 2, (uint32_t*)(base + o_heavy));
       // Buckets too large for k_combine exist only if some bucket spans more than LIGHT_SLOTS/2 chunks.
-      const bool heavy = (size_t)max_bucket > (size_t)(LIGHT_SLOTS / 2 - 1) * ACC_K0;
-      size_t slots = 2 * chunks0;
-      for (int l = 1; heavy; l++) {
-        const size_t chunks = (slots + ACC_K - 1) / ACC_K;
-        k_accumulate<F, false><<<(unsigned)((chunks + 255) / 256), 256, 0, st>>>(
-            jt, l, (uint32_t)slots, (uint32_t*)(base + o_keys[l]), nullptr, (XYZZ<F>*)(base + o_pts[l]), off,
-            (uint32_t*)(base + o_keys[l + 1]), (XYZZ<F>*)(base + o_pts[l + 1]), bsum, err);
-        if (chunks <= 1) break;
-        slots = 2 * chunks;
-      }
+      if ((size_t)max_bucket > (size_t)(LIGHT_SLOTS / 2 - 1) * ACC_K0)
+        k_heavy<F><<<256, 256, 0, st>>>(err + 2, (const uint32_t*)(base + o_heavy), off, keys1, pts1, bsum);
     }
   }
   {
