@@ -52,20 +52,6 @@ Fr load_fr(const uint64_t* p) {
   return r;
 }
 
-struct Timer {
-  zg16_ctx* ctx;
-  hipEvent_t a, b;
-  explicit Timer(zg16_ctx* c) : ctx(c), a(c->ev[0]), b(c->ev[1]) {}
-  void start() { (void)hipEventRecord(a, ctx->stream); }
-  float stop() {
-    (void)hipEventRecord(b, ctx->stream);
-    (void)hipEventSynchronize(b);
-    float ms = 0;
-    (void)hipEventElapsedTime(&ms, a, b);
-    return ms;
-  }
-};
-
 // Device witness z = z_in || z_aux in scratch slot 3.
 zg16_status stage_witness(zg16_ctx* ctx, const zg16_r1cs* r, const uint64_t* z_in, const uint64_t* z_aux,
                           int on_device, Fr** z_out) {
@@ -111,7 +97,7 @@ zg16_status msm_entry(zg16_ctx* ctx, const uint64_t* bases, size_t n_bases, cons
   if (n_scalars) ZG_HIP(ctx, hipMemcpyAsync(d_s, scalars, s_bytes, hipMemcpyHostToDevice, ctx->stream));
   if (m_bytes) ZG_HIP(ctx, hipMemcpyAsync(d_m, map.data(), m_bytes, hipMemcpyHostToDevice, ctx->stream));
   ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  MsmJob<F> job = {d_b, d_s, density ? d_m : nullptr, n_bases, 0, 0};
+  MsmJob<F> job = {d_b, d_s, density ? d_m : nullptr, n_bases, 0, 0, 0};
   XYZZ<F> res;
   ZG_TRY(run(ctx, &job, 1, &res));
   *out = to_affine(res);
@@ -136,6 +122,10 @@ zg16_status zg16_ctx_create(int device_id, zg16_ctx** out) {
     return ZG16_ERR_DEVICE;
   }
   ctx->stream = ctx->own_stream;
+  if (hipHostMalloc(&ctx->pinned, 2 * MSM_PINNED_BYTES, hipHostMallocDefault) != hipSuccess) {
+    delete ctx;
+    return ZG16_ERR_DEVICE;
+  }
   for (auto& e : ctx->ev)
     if (hipEventCreate(&e) != hipSuccess) {
       delete ctx;
@@ -156,6 +146,7 @@ void zg16_ctx_destroy(zg16_ctx* ctx) {
     if (e) (void)hipEventDestroy(e);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
+  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   delete ctx;
 }
 
@@ -306,62 +297,82 @@ zg16_status zg16_prove_partial(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1cs
   ZG_HIP(ctx, hipSetDevice(ctx->device));
   zg16_timings& tm = ctx->timings;
   tm = zg16_timings();
-  hipEvent_t e_begin = ctx->ev[2], e_end = ctx->ev[3];
-  ZG_HIP(ctx, hipEventRecord(e_begin, ctx->stream));
-  Timer t(ctx);
+  // Stage boundaries are events; nothing below waits on the host until every kernel is enqueued.
+  enum { E_BEGIN, E_Z, E_SPMV, E_NTT, E_G1, E_G2_BEGIN, E_G2_END, E_END };
+  hipEvent_t* ev = ctx->ev;
+  hipStream_t st = ctx->stream, aux = ctx->aux_stream;
   const size_t m = (size_t)1 << r->log_m;
+  const uint32_t tc = pk->table_c;
+  auto stride = [&](size_t lo, size_t hi) { return tc ? hi - lo : (size_t)0; };
 
-  t.start();
+  ZG_HIP(ctx, hipEventRecord(ev[E_BEGIN], st));
   Fr* z;
   ZG_TRY(stage_witness(ctx, r, z_in, z_aux, on_device, &z));
   Fr* abc;
   ZG_TRY(scratch_get(ctx, 4, 3 * m * sizeof(Fr), (void**)&abc));
   Fr *a = abc, *b = abc + m, *c = abc + 2 * m;
   if (m > r->n_rows)
-    for (Fr* p : {a, b, c}) ZG_HIP(ctx, hipMemsetAsync(p + r->n_rows, 0, (m - r->n_rows) * sizeof(Fr), ctx->stream));
-  tm.upload_ms = t.stop();
+    for (Fr* p : {a, b, c}) ZG_HIP(ctx, hipMemsetAsync(p + r->n_rows, 0, (m - r->n_rows) * sizeof(Fr), st));
+  ZG_HIP(ctx, hipEventRecord(ev[E_Z], st));
 
-  t.start();
+  // The G2 multiexp needs only the witness: it runs on the second stream beside the row
+  // evaluation, the transforms and the G1 multiexps.
+  MsmPending pend_g2, pend_g1;
+  {
+    ZG_HIP(ctx, hipStreamWaitEvent(aux, ev[E_Z], 0));
+    ZG_HIP(ctx, hipEventRecord(ev[E_G2_BEGIN], aux));
+    MsmJob<Fq2> jb = {pk->b2, z, r->b_map + pk->lo_b, pk->hi_b - pk->lo_b, stride(pk->lo_b, pk->hi_b), tc, 0};
+    ZG_TRY(msm_launch<Fq2>(ctx, aux, 2, (char*)ctx->pinned + MSM_PINNED_BYTES, &jb, 1, 1, &pend_g2));
+    ZG_HIP(ctx, hipEventRecord(ev[E_G2_END], aux));
+  }
+
   ZG_TRY(spmv_device(ctx, r, z, a, b, c));
-  tm.spmv_ms = t.stop();
-
-  t.start();
+  ZG_HIP(ctx, hipEventRecord(ev[E_SPMV], st));
   ZG_TRY(h_pipeline_device(ctx, a, b, c, r->log_m));
-  tm.ntt_ms = t.stop();
+  ZG_HIP(ctx, hipEventRecord(ev[E_NTT], st));
 
-  t.start();
-  G1XYZZ hl, qa, qb1;
-  G2XYZZ qb2;
+  // One G1 launch, three results: h + l (both only enter C), the a query, the b_g1 query.
+  G1XYZZ g1[3];
   {
     // h covers coefficients 0..m-2; this shard owns [lo_h, hi_h) clipped to that range
     const size_t hi_h = pk->hi_h < m - 1 ? pk->hi_h : m - 1;
     const size_t lo_h = pk->lo_h < hi_h ? pk->lo_h : hi_h;
-    const uint32_t tc = pk->table_c;
-    auto stride = [&](size_t lo, size_t hi) { return tc ? hi - lo : (size_t)0; };
     // the h table is laid out for the whole shard; skip the points below lo_h when the range was clipped
-    MsmJob<Fq> jobs[2] = {{pk->h + (lo_h - pk->lo_h), a + lo_h, nullptr, hi_h - lo_h, stride(pk->lo_h, pk->hi_h), tc},
-                          {pk->l, z + r->n_in + pk->lo_l, nullptr, pk->hi_l - pk->lo_l, stride(pk->lo_l, pk->hi_l), tc}};
-    ZG_TRY(msm_g1_device(ctx, jobs, 2, &hl));
-    MsmJob<Fq> ja = {pk->a, z, r->a_map + pk->lo_a, pk->hi_a - pk->lo_a, stride(pk->lo_a, pk->hi_a), tc};
-    ZG_TRY(msm_g1_device(ctx, &ja, 1, &qa));
-    MsmJob<Fq> jb = {pk->b1, z, r->b_map + pk->lo_b, pk->hi_b - pk->lo_b, stride(pk->lo_b, pk->hi_b), tc};
-    ZG_TRY(msm_g1_device(ctx, &jb, 1, &qb1));
+    MsmJob<Fq> jobs[4] = {
+        {pk->h + (lo_h - pk->lo_h), a + lo_h, nullptr, hi_h - lo_h, stride(pk->lo_h, pk->hi_h), tc, 0},
+        {pk->l, z + r->n_in + pk->lo_l, nullptr, pk->hi_l - pk->lo_l, stride(pk->lo_l, pk->hi_l), tc, 0},
+        {pk->a, z, r->a_map + pk->lo_a, pk->hi_a - pk->lo_a, stride(pk->lo_a, pk->hi_a), tc, 1},
+        {pk->b1, z, r->b_map + pk->lo_b, pk->hi_b - pk->lo_b, stride(pk->lo_b, pk->hi_b), tc, 2}};
+    if (tc) {
+      ZG_TRY(msm_launch<Fq>(ctx, st, 1, ctx->pinned, jobs, 4, 3, &pend_g1));
+      ZG_HIP(ctx, hipEventRecord(ev[E_G1], st));
+      ZG_HIP(ctx, hipStreamWaitEvent(st, ev[E_G2_END], 0));
+      ZG_HIP(ctx, hipEventRecord(ev[E_END], st));
+      ZG_HIP(ctx, hipEventSynchronize(ev[E_END]));
+      ZG_TRY(msm_collect<Fq>(ctx, &pend_g1, g1));
+    } else {
+      // without window tables every result needs its own bucket sets: three launches in turn
+      ZG_TRY(msm_g1_device(ctx, jobs, 2, &g1[0]));
+      ZG_TRY(msm_g1_device(ctx, jobs + 2, 1, &g1[1]));
+      ZG_TRY(msm_g1_device(ctx, jobs + 3, 1, &g1[2]));
+      ZG_HIP(ctx, hipEventRecord(ev[E_G1], st));
+      ZG_HIP(ctx, hipStreamWaitEvent(st, ev[E_G2_END], 0));
+      ZG_HIP(ctx, hipEventRecord(ev[E_END], st));
+      ZG_HIP(ctx, hipEventSynchronize(ev[E_END]));
+    }
   }
-  tm.msm_g1_ms = t.stop();
-  t.start();
-  {
-    MsmJob<Fq2> jb = {pk->b2, z, r->b_map + pk->lo_b, pk->hi_b - pk->lo_b, pk->table_c ? pk->hi_b - pk->lo_b : (size_t)0,
-                      pk->table_c};
-    ZG_TRY(msm_g2_device(ctx, &jb, 1, &qb2));
-  }
-  tm.msm_g2_ms = t.stop();
-  memcpy(out->hl, &hl, sizeof hl);
-  memcpy(out->a, &qa, sizeof qa);
-  memcpy(out->b1, &qb1, sizeof qb1);
+  G2XYZZ qb2;
+  ZG_TRY(msm_collect<Fq2>(ctx, &pend_g2, &qb2));
+  memcpy(out->hl, &g1[0], sizeof g1[0]);
+  memcpy(out->a, &g1[1], sizeof g1[1]);
+  memcpy(out->b1, &g1[2], sizeof g1[2]);
   memcpy(out->b2, &qb2, sizeof qb2);
-  ZG_HIP(ctx, hipEventRecord(e_end, ctx->stream));
-  ZG_HIP(ctx, hipEventSynchronize(e_end));
-  ZG_HIP(ctx, hipEventElapsedTime(&tm.total_ms, e_begin, e_end));
+  ZG_HIP(ctx, hipEventElapsedTime(&tm.upload_ms, ev[E_BEGIN], ev[E_Z]));
+  ZG_HIP(ctx, hipEventElapsedTime(&tm.spmv_ms, ev[E_Z], ev[E_SPMV]));
+  ZG_HIP(ctx, hipEventElapsedTime(&tm.ntt_ms, ev[E_SPMV], ev[E_NTT]));
+  ZG_HIP(ctx, hipEventElapsedTime(&tm.msm_g1_ms, ev[E_NTT], ev[E_G1]));
+  ZG_HIP(ctx, hipEventElapsedTime(&tm.msm_g2_ms, ev[E_G2_BEGIN], ev[E_G2_END]));  // overlaps the stages above
+  ZG_HIP(ctx, hipEventElapsedTime(&tm.total_ms, ev[E_BEGIN], ev[E_END]));
   profile_collect(ctx);
   return ZG16_OK;
 }

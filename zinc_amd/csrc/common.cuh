@@ -43,9 +43,8 @@ struct zg16_ctx {
   hipStream_t stream = nullptr;      // stream all kernels are issued on
   hipStream_t own_stream = nullptr;  // created by the context
   hipStream_t aux_stream = nullptr;  // second stream for overlapping independent stages
-  hipStream_t msm_stream[4] = {};    // one per concurrent multiexp of a proof
-  void* pinned = nullptr;            // page-locked host memory for small asynchronous read-backs
-  hipEvent_t ev[8] = {};
+  void* pinned = nullptr;            // page-locked host memory for asynchronous result read-backs
+  hipEvent_t ev[12] = {};
   std::string last_error = "";
   std::map<unsigned, zg::NttDomain*> domains;  // per log2 size
   // grow-only device scratch arenas, one per independent consumer
@@ -161,7 +160,7 @@ zg16_status ntt_device(zg16_ctx* ctx, Fr* data, unsigned log_n, bool inverse, bo
 // the icoset_fft output whose first m-1 entries are the H coefficients.  b, c are clobbered.
 zg16_status h_pipeline_device(zg16_ctx* ctx, Fr* a, Fr* b, Fr* c, unsigned log_m);
 
-// One multiexp term list: result += sum_k scalar(k) * bases[k], k < n, where
+// One multiexp term list: result[group] += sum_k scalar(k) * bases[k], k < n, where
 // scalar(k) = scalars[index ? index[k] : k] (Montgomery Fr, device memory).
 template <class F>
 struct MsmJob {
@@ -172,6 +171,7 @@ struct MsmJob {
   // Non-zero when `bases` is a window table: bases[w * table_stride + k] = 2^(table_c * w) * P_k.
   size_t table_stride;
   uint32_t table_c;
+  int group;  // which of the launch's results this job is summed into
 };
 // Window width / count used for key tables, and the kernel that fills windows 1..W-1 of a table whose
 // window 0 (n points, stride n) is already in place.
@@ -179,25 +179,26 @@ uint32_t msm_table_window(size_t largest_query);
 uint32_t msm_table_windows(uint32_t c);
 template <class F>
 zg16_status msm_build_table(zg16_ctx* ctx, Affine<F>* table, size_t n, uint32_t c);
-// Sum of several jobs as one multiexp; writes one XYZZ point to host memory `out`.
+// Blocking forms on ctx->stream: the sum of several jobs as one multiexp, one XYZZ point to `out_host`.
 zg16_status msm_g1_device(zg16_ctx* ctx, const MsmJob<Fq>* jobs, int njobs, G1XYZZ* out_host);
 zg16_status msm_g2_device(zg16_ctx* ctx, const MsmJob<Fq2>* jobs, int njobs, G2XYZZ* out_host);
 
-// The same multiexp in three stages so that several can be in flight on different streams:
-// msm_sort launches digits / scan / counting sort and an asynchronous read-back of the entry
-// counts; after that stream is idle msm_reduce launches accumulation and reduction; after it is
-// idle again msm_finish does the host part.  `pinned` is >= 16 KiB of page-locked host memory.
-struct MsmPlanBase {
-  virtual ~MsmPlanBase() {}
+// Asynchronous form, so that several multiexps can be in flight on different streams.  msm_launch
+// enqueues every kernel of the multiexp on `st` plus a copy of the results into `pinned`
+// (MSM_PINNED_BYTES of page-locked host memory) and returns without waiting; once `st` is idle
+// msm_collect turns the block into `ngroups` points.  Jobs of one launch may form several groups
+// (independent sums) only when every job brings a window table of the same width.
+static constexpr size_t MSM_PINNED_BYTES = 32768;
+struct MsmPending {
+  void* pinned = nullptr;
+  uint32_t nsets = 0, ngroups = 0, c = 0, shared = 0;
+  int acc_kernel = 0;  // KernelId whose work units (additions) are known only after the run
 };
 template <class F>
-zg16_status msm_sort(zg16_ctx* ctx, hipStream_t st, int scratch_slot, void* pinned, const MsmJob<F>* jobs, int njobs,
-                     MsmPlanBase** plan);
+zg16_status msm_launch(zg16_ctx* ctx, hipStream_t st, int scratch_slot, void* pinned, const MsmJob<F>* jobs, int njobs,
+                       int ngroups, MsmPending* pend);
 template <class F>
-zg16_status msm_reduce(zg16_ctx* ctx, MsmPlanBase* plan);
-template <class F>
-zg16_status msm_finish(zg16_ctx* ctx, MsmPlanBase* plan, XYZZ<F>* out_host);
-static constexpr size_t MSM_PINNED_BYTES = 16384;
+zg16_status msm_collect(zg16_ctx* ctx, const MsmPending* pend, XYZZ<F>* out);
 
 void ntt_free_domains(zg16_ctx* ctx);
 

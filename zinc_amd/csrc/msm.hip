@@ -13,7 +13,7 @@
 //    2^(c-1) buckets: the bucket reduction shrinks W-fold and there is no window recombination.
 //  * per-window buckets (stand-alone multiexp on caller-supplied bases): W bucket sets, host Horner.
 //
-// Pipeline (one stream):
+// Pipeline (one stream, no host synchronisation until the result is read):
 //   1. k_digits<COUNT>   : Montgomery scalar -> canonical -> W signed c-bit digits; histogram
 //   2. k_scan_*          : exclusive scan of bucket sizes -> bucket offsets (+ largest bucket)
 //   3. k_digits<SCATTER> : counting sort of (bucket, window, base index, sign) entries
@@ -53,6 +53,7 @@ struct JobTable {
   const uint32_t* index[MAX_JOBS];
   uint32_t stride[MAX_JOBS];     // table stride (points per window); unused with per-window buckets
   uint32_t start[MAX_JOBS + 1];  // prefix offsets of the concatenated term list
+  uint32_t group[MAX_JOBS];      // which result (bucket set) the job's terms are summed into
   int njobs;
 };
 
@@ -61,8 +62,9 @@ struct MsmShape {
   uint32_t c;        // window bits
   uint32_t W;        // windows
   uint32_t B;        // buckets per bucket set = 2^(c-1)
-  uint32_t nb;       // digit buckets (B shared, W*B per-window); bucket nb collects the unit scalars
-  uint32_t shared;   // 1: all windows share one bucket set (table lookup), 0: one set per window
+  uint32_t nb;       // digit buckets (G*B shared, W*B per-window); bucket nb + g collects group g's unit scalars
+  uint32_t shared;   // 1: all windows share one bucket set per group (table lookup), 0: one set per window
+  uint32_t G;        // groups = independent results (1 unless shared)
 };
 
 template <class F>
@@ -75,8 +77,7 @@ ZG_D int find_job(const JobTable<F>& jt, uint32_t i) {
 }
 
 template <class F>
-ZG_D Fr load_scalar(const JobTable<F>& jt, uint32_t i) {
-  const int j = find_job(jt, i);
+ZG_D Fr load_scalar(const JobTable<F>& jt, uint32_t i, int j) {
   const uint32_t local = i - jt.start[j];
   const uint32_t si = jt.index[j] ? jt.index[j][local] : local;
   return jt.scalars[j][si];
@@ -114,21 +115,28 @@ __global__ __launch_bounds__(256) void k_digits(JobTable<F> jt, MsmShape sh, uin
                                                 uint32_t* __restrict__ cursor,
                                                 uint32_t* __restrict__ ent, uint32_t* __restrict__ keys) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < sh.n; i += gridDim.x * blockDim.x) {
-    const Fr s = from_mont(load_scalar(jt, i));
+    const int j = find_job(jt, i);
+    const Fr s = from_mont(load_scalar(jt, i, j));
     if (s.is_zero()) continue;
+    const uint32_t g = jt.group[j];
     bool is_one = s.v[0] == 1;
 #pragma unroll
     for (int k = 1; k < 8; k++) is_one = is_one && s.v[k] == 0;
     if (is_one) {
-      if (SCATTER) {
-        const uint32_t pos = wave_agg_inc(&cursor[sh.nb]);
-        ent[pos] = i;
-        keys[pos] = sh.nb;
-      } else {
-        wave_agg_inc(&hist[sh.nb]);
+      // lanes of one wave may belong to different groups only at a job boundary: aggregate per group
+      for (uint32_t gg = 0; gg < sh.G; gg++) {
+        if (g != gg) continue;
+        if (SCATTER) {
+          const uint32_t pos = wave_agg_inc(&cursor[sh.nb + gg]);
+          ent[pos] = i;
+          keys[pos] = sh.nb + gg;
+        } else {
+          wave_agg_inc(&hist[sh.nb + gg]);
+        }
       }
       continue;
     }
+    const uint32_t set_base = sh.shared ? g * sh.B : 0;
     uint32_t carry = 0;
     for (uint32_t w = 0; w < sh.W; w++) {
       uint32_t d = extract_bits(s.v, w * sh.c, sh.c) + carry;
@@ -140,7 +148,7 @@ __global__ __launch_bounds__(256) void k_digits(JobTable<F> jt, MsmShape sh, uin
         carry = 1;
       }
       if (d) {
-        const uint32_t bucket = sh.shared ? d - 1 : w * sh.B + d - 1;
+        const uint32_t bucket = sh.shared ? set_base + d - 1 : w * sh.B + d - 1;
         if (SCATTER) {
           const uint32_t pos = atomicAdd(&cursor[bucket], 1u);
           ent[pos] = i | (neg << 31);
@@ -155,22 +163,18 @@ __global__ __launch_bounds__(256) void k_digits(JobTable<F> jt, MsmShape sh, uin
 
 // Exclusive scan of hist[0..count) into off[0..count] (and a copy in cursor[0..count)) in three
 // launches: per-workgroup scans of 4096 counters, a scan of the workgroup totals, a fix-up.
-// stat[0] receives the largest counter among hist[0..count-1) (the last counter is the unit-scalar
-// bucket, which has its own path).
 static constexpr uint32_t SCAN_TILE = 4096;
 
 __global__ __launch_bounds__(256) void k_scan_local(const uint32_t* __restrict__ hist, uint32_t count,
-                                                    uint32_t* __restrict__ off, uint32_t* __restrict__ tile_sum,
-                                                    uint32_t* __restrict__ stat) {
+                                                    uint32_t* __restrict__ off, uint32_t* __restrict__ tile_sum) {
   __shared__ uint32_t part[256];
   const uint32_t tid = threadIdx.x;
   const uint32_t base = blockIdx.x * SCAN_TILE + tid * 16;
-  uint32_t v[16], s = 0, mx = 0;
+  uint32_t v[16], s = 0;
 #pragma unroll
   for (int i = 0; i < 16; i++) {
     v[i] = base + i < count ? hist[base + i] : 0;
     s += v[i];
-    if (base + i + 1 < count && v[i] > mx) mx = v[i];
   }
   part[tid] = s;
   __syncthreads();
@@ -187,7 +191,6 @@ __global__ __launch_bounds__(256) void k_scan_local(const uint32_t* __restrict__
     run += v[i];
   }
   if (tid == 255) tile_sum[blockIdx.x] = part[255];
-  if (mx) atomicMax(stat, mx);
 }
 
 // One workgroup: exclusive scan of tile_sum[0..ntiles) in place; tile_sum[ntiles] = grand total.
@@ -233,11 +236,11 @@ ZG_D bool bucket_is_light(uint32_t s, uint32_t e) {
   return 2 * ((e - 1) / ACC_K0 - s / ACC_K0 + 1) <= (uint32_t)LIGHT_SLOTS;
 }
 
-// Level 0 of the segmented reduction: lane t owns sorted entries [64t, 64t+64) whatever the bucket
-// sizes are.  A run that lies inside the chunk finishes its bucket; a run cut by a chunk edge
+// Level 0 of the segmented reduction (the grid covers the largest possible entry count; the actual
+// one is read from off[nb]): lane t owns sorted entries [64t, 64t+64) whatever the bucket sizes are.  A run that lies inside the chunk finishes its bucket; a run cut by a chunk edge
 // leaves a partial sum in slot 2t (first run) or 2t+1 (last run) for k_combine / k_heavy.
 template <class F>
-__global__ __launch_bounds__(256, kMinWaves<F>) void k_accumulate(JobTable<F> jt, uint32_t nslots,
+__global__ __launch_bounds__(256, kMinWaves<F>) void k_accumulate(JobTable<F> jt, uint32_t nb,
                                                                   const uint32_t* __restrict__ keys_in,
                                                                   const uint32_t* __restrict__ ent_in,
                                                                   const uint32_t* __restrict__ off,
@@ -248,6 +251,7 @@ __global__ __launch_bounds__(256, kMinWaves<F>) void k_accumulate(JobTable<F> jt
   constexpr uint32_t K = ACC_K0;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t lo = t * K;
+  const uint32_t nslots = off[nb];  // digit entries; the unit-scalar entries behind them go to k_sum_range
   if (lo >= nslots) return;
   const uint32_t hi = lo + K < nslots ? lo + K : nslots;
   uint32_t cur = KEY_INVALID;
@@ -427,13 +431,17 @@ __global__ __launch_bounds__(256, kMinWaves<F>) void k_sum_partials(const XYZZ<F
   if (tid == 0) out[w] = acc;
 }
 
-// Plain sum of the bases named by ent[lo..hi) (the scalars equal to one): each lane adds a
-// contiguous share, the workgroup tree-adds, one partial per workgroup.
+// Plain sum of the bases whose scalar equals one, group blockIdx.y: the entries are
+// ent[off[nb+g] .. off[nb+g+1]).  Each lane adds a contiguous share, the workgroup tree-adds, one
+// partial per workgroup at part[g * gridDim.x + blockIdx.x].
 template <class F>
-__global__ __launch_bounds__(256, kMinWaves<F>) void k_sum_range(JobTable<F> jt, const uint32_t* __restrict__ ent, uint32_t lo,
-                                                   uint32_t hi, XYZZ<F>* __restrict__ part,
-                                                   uint32_t* __restrict__ err_flag) {
+__global__ __launch_bounds__(256, kMinWaves<F>) void k_sum_range(JobTable<F> jt, const uint32_t* __restrict__ ent,
+                                                                   const uint32_t* __restrict__ off, uint32_t nb,
+                                                                   XYZZ<F>* __restrict__ part,
+                                                                   uint32_t* __restrict__ err_flag) {
   __shared__ XYZZ<F> sh[128];
+  const uint32_t g = blockIdx.y;
+  const uint32_t lo = off[nb + g], hi = off[nb + g + 1];
   const uint32_t nthreads = gridDim.x * 256, t = blockIdx.x * 256 + threadIdx.x;
   const uint32_t per = (hi - lo + nthreads - 1) / nthreads;
   const uint32_t a = lo + t * per < hi ? lo + t * per : hi;
@@ -445,7 +453,7 @@ __global__ __launch_bounds__(256, kMinWaves<F>) void k_sum_range(JobTable<F> jt,
     add_mixed(acc, p);
   }
   block_sum(acc, sh);
-  if (threadIdx.x == 0) part[blockIdx.x] = acc;
+  if (threadIdx.x == 0) part[(size_t)g * gridDim.x + blockIdx.x] = acc;
 }
 
 // table[w*stride + i] = 2^(c*w) * table[i] for w in 1..W-1 (window 0 is already in place).
@@ -507,10 +515,14 @@ zg16_status msm_build_table(zg16_ctx* ctx, Affine<F>* table, size_t n, uint32_t 
 template zg16_status msm_build_table<Fq>(zg16_ctx*, Affine<Fq>*, size_t, uint32_t);
 template zg16_status msm_build_table<Fq2>(zg16_ctx*, Affine<Fq2>*, size_t, uint32_t);
 
+// Result block in page-locked host memory: [0] identity-base flag, then (sets + groups) XYZZ points.
+static constexpr size_t PINNED_POINTS = 256;
+
 template <class F>
-static zg16_status msm_run(zg16_ctx* ctx, int scratch_slot, const MsmJob<F>* jobs, int njobs,
-                           XYZZ<F>* out_host) {
+zg16_status msm_launch(zg16_ctx* ctx, hipStream_t st, int scratch_slot, void* pinned, const MsmJob<F>* jobs, int njobs,
+                       int ngroups, MsmPending* pend) {
   if (njobs > MAX_JOBS) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "too many multiexp jobs");
+  if (ngroups < 1 || ngroups > MAX_JOBS) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "bad multiexp group count");
   JobTable<F> jt = {};
   size_t n = 0;
   int nj = 0;
@@ -518,11 +530,13 @@ static zg16_status msm_run(zg16_ctx* ctx, int scratch_slot, const MsmJob<F>* job
   uint32_t table_c = 0;
   for (int j = 0; j < njobs; j++) {
     if (!jobs[j].n) continue;
+    if (jobs[j].group < 0 || jobs[j].group >= ngroups) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "bad multiexp group");
     jt.bases[nj] = jobs[j].bases;
     jt.scalars[nj] = jobs[j].scalars;
     jt.index[nj] = jobs[j].index;
     jt.stride[nj] = (uint32_t)jobs[j].table_stride;
     jt.start[nj] = (uint32_t)n;
+    jt.group[nj] = (uint32_t)jobs[j].group;
     if (!jobs[j].table_stride || (table_c && jobs[j].table_c != table_c)) all_tables = false;
     table_c = jobs[j].table_c;
     n += jobs[j].n;
@@ -530,43 +544,52 @@ static zg16_status msm_run(zg16_ctx* ctx, int scratch_slot, const MsmJob<F>* job
   }
   jt.njobs = nj;
   for (int j = nj; j <= MAX_JOBS; j++) jt.start[j] = (uint32_t)n;
-  *out_host = XYZZ<F>::inf();
+  pend->pinned = pinned;
+  pend->ngroups = (uint32_t)ngroups;
+  pend->nsets = 0;
   if (n == 0) return ZG16_OK;
   if (n >= 0x7fffffffu) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "multiexp of %zu terms exceeds 2^31", n);
+  if (!all_tables && ngroups != 1) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "grouped multiexp needs window tables");
 
   MsmShape sh;
   sh.n = (uint32_t)n;
   sh.shared = all_tables ? 1 : 0;
+  sh.G = (uint32_t)ngroups;
   sh.c = sh.shared ? table_c : pick_window(n);
   sh.W = (255 + sh.c - 1) / sh.c;
   sh.B = 1u << (sh.c - 1);
-  sh.nb = sh.shared ? sh.B : sh.W * sh.B;
+  sh.nb = sh.shared ? sh.G * sh.B : sh.W * sh.B;
   if (!sh.shared)
     for (int j = 0; j < nj; j++) jt.stride[j] = 0;
-  const uint32_t nsets = sh.shared ? 1 : sh.W;
+  const uint32_t nsets = sh.shared ? sh.G : sh.W;
   const size_t max_entries = (size_t)sh.W * n;
   if (max_entries >= 0xfffffff0ull) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "multiexp too large for 32-bit entry offsets");
+  if (sh.nb + sh.G > KEY_MASK) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "too many multiexp buckets");
+  if ((nsets + sh.G) * sizeof(XYZZ<F>) + PINNED_POINTS > MSM_PINNED_BYTES)
+    return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "multiexp result block too large");
+  const uint32_t ncount = sh.nb + sh.G;  // counters: digit buckets, then one unit-scalar bucket per group
 
   // scratch layout
   auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
   size_t o = 0;
-  const size_t o_hist = o;   o += align((sh.nb + 1) * 4);
-  const size_t o_off = o;    o += align((sh.nb + 2) * 4);
-  const size_t o_cur = o;    o += align((sh.nb + 1) * 4);
-  const size_t o_err = o;    o += 256;  // [0] identity-base flag, [1] largest digit bucket, [2] heavy buckets
+  const size_t o_hist = o;   o += align((size_t)ncount * 4);
+  const size_t o_off = o;    o += align((size_t)(ncount + 1) * 4);
+  const size_t o_cur = o;    o += align((size_t)ncount * 4);
+  const size_t o_err = o;    o += 256;  // [0] identity-base flag, [2] number of heavy buckets
   const size_t o_ent = o;    o += align(max_entries * 4);
   const size_t o_key0 = o;   o += align(max_entries * 4);
-  const size_t max_slots = 2 * ((max_entries + ACC_K0 - 1) / ACC_K0);
-  const size_t o_keys1 = o;  o += align(max_slots * 4);
-  const size_t o_pts1 = o;   o += align(max_slots * sizeof(XYZZ<F>));
+  const size_t max_chunks = (max_entries + ACC_K0 - 1) / ACC_K0;
+  const size_t o_keys1 = o;  o += align(2 * max_chunks * 4);
+  const size_t o_pts1 = o;   o += align(2 * max_chunks * sizeof(XYZZ<F>));
   const size_t o_heavy = o;  o += align((size_t)sh.nb * 4);
-  const size_t o_bsum = o;   o += align((size_t)(sh.nb + 1) * sizeof(XYZZ<F>));
-  const size_t o_wsum = o;   o += align((size_t)(nsets + 1) * sizeof(XYZZ<F>));
-  const uint32_t ntiles = (sh.nb + 1 + SCAN_TILE - 1) / SCAN_TILE;
+  const size_t o_bsum = o;   o += align((size_t)sh.nb * sizeof(XYZZ<F>));
+  const size_t o_wsum = o;   o += align((size_t)(nsets + sh.G) * sizeof(XYZZ<F>));
+  const uint32_t ntiles = (ncount + SCAN_TILE - 1) / SCAN_TILE;
   const uint32_t red_blocks = (sh.B + 256 * RED_SEG - 1) / (256 * RED_SEG);
-  const uint32_t max_ones_blocks = 1024;
+  uint32_t ones_blocks = (uint32_t)((n + 256 * 16 - 1) / (256 * 16));
+  if (ones_blocks > 1024) ones_blocks = 1024;
   const size_t o_tiles = o;  o += align((size_t)(ntiles + 1) * 4);
-  const size_t o_part = o;   o += align((size_t)(nsets * red_blocks + max_ones_blocks) * sizeof(XYZZ<F>));
+  const size_t o_part = o;   o += align((size_t)(nsets * red_blocks + sh.G * ones_blocks) * sizeof(XYZZ<F>));
   char* base;
   ZG_TRY(scratch_get(ctx, scratch_slot, o, (void**)&base));
   uint32_t* hist = (uint32_t*)(base + o_hist);
@@ -575,93 +598,112 @@ static zg16_status msm_run(zg16_ctx* ctx, int scratch_slot, const MsmJob<F>* job
   uint32_t* err = (uint32_t*)(base + o_err);
   uint32_t* ent = (uint32_t*)(base + o_ent);
   uint32_t* key0 = (uint32_t*)(base + o_key0);
+  uint32_t* keys1 = (uint32_t*)(base + o_keys1);
+  XYZZ<F>* pts1 = (XYZZ<F>*)(base + o_pts1);
   XYZZ<F>* bsum = (XYZZ<F>*)(base + o_bsum);
   XYZZ<F>* wsum = (XYZZ<F>*)(base + o_wsum);
   uint32_t* tiles = (uint32_t*)(base + o_tiles);
   XYZZ<F>* part = (XYZZ<F>*)(base + o_part);
-  hipStream_t st = ctx->stream;
+  XYZZ<F>* ones_part = part + (size_t)nsets * red_blocks;
 
   ZG_HIP(ctx, hipMemsetAsync(base, 0, o_ent, st));  // hist, off, cursor, err
-  ZG_HIP(ctx, hipMemsetAsync(bsum, 0, (size_t)(sh.nb + 1) * sizeof(XYZZ<F>), st));
+  ZG_HIP(ctx, hipMemsetAsync(bsum, 0, (size_t)sh.nb * sizeof(XYZZ<F>), st));
   const unsigned dgrid = (unsigned)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256);
   constexpr bool is_g2 = sizeof(F) > sizeof(Fq);
   {
-    KernelTimer kt(ctx, K_MSM_DIGITS, (double)n);
+    KernelTimer kt(ctx, K_MSM_DIGITS, (double)n, st);
     k_digits<F, false><<<dgrid, 256, 0, st>>>(jt, sh, hist, cursor, ent, key0);
   }
   {
-    KernelTimer kt(ctx, K_MSM_SCAN, (double)sh.nb);
-    k_scan_local<<<ntiles, 256, 0, st>>>(hist, sh.nb + 1, off, tiles, err + 1);
+    KernelTimer kt(ctx, K_MSM_SCAN, (double)ncount, st);
+    k_scan_local<<<ntiles, 256, 0, st>>>(hist, ncount, off, tiles);
     k_scan_tiles<<<1, 1024, 0, st>>>(tiles, ntiles);
-    k_scan_fixup<<<(sh.nb + 2 + 255) / 256, 256, 0, st>>>(off, cursor, sh.nb + 1, tiles, ntiles);
+    k_scan_fixup<<<(ncount + 1 + 255) / 256, 256, 0, st>>>(off, cursor, ncount, tiles, ntiles);
   }
   {
-    KernelTimer kt(ctx, K_MSM_DIGITS, (double)n);
+    KernelTimer kt(ctx, K_MSM_DIGITS, (double)n, st);
     k_digits<F, true><<<dgrid, 256, 0, st>>>(jt, sh, hist, cursor, ent, key0);
   }
-  uint32_t tail[2] = {0, 0};  // start of the unit-scalar range, total entries
-  uint32_t max_bucket = 0;
-  ZG_HIP(ctx, hipMemcpyAsync(tail, off + sh.nb, 8, hipMemcpyDeviceToHost, st));
-  ZG_HIP(ctx, hipMemcpyAsync(&max_bucket, err + 1, 4, hipMemcpyDeviceToHost, st));
-  ZG_HIP(ctx, hipStreamSynchronize(st));
-  // the scalars equal to one: a plain tree sum, kept out of the segmented reduction
-  const uint32_t n_ones = tail[1] - tail[0];
-  if (n_ones) {
-    uint32_t g = (n_ones + 256 * 16 - 1) / (256 * 16);
-    if (g > max_ones_blocks) g = max_ones_blocks;
-    KernelTimer kt(ctx, is_g2 ? K_MSM_ONES_G2 : K_MSM_ONES_G1, (double)n_ones);
-    k_sum_range<F><<<g, 256, 0, st>>>(jt, ent, tail[0], tail[1], part + (size_t)nsets * red_blocks, err);
-    k_sum_partials<F><<<1, 256, 0, st>>>(part + (size_t)nsets * red_blocks, g, wsum + nsets);
-  } else {
-    ZG_HIP(ctx, hipMemsetAsync(wsum + nsets, 0, sizeof(XYZZ<F>), st));
-  }
-  const size_t entries = tail[0];
-  if (entries) {
-    const size_t chunks0 = (entries + ACC_K0 - 1) / ACC_K0;
-    uint32_t* keys1 = (uint32_t*)(base + o_keys1);
-    XYZZ<F>* pts1 = (XYZZ<F>*)(base + o_pts1);
-    {
-      KernelTimer kt(ctx, is_g2 ? K_MSM_ACC0_G2 : K_MSM_ACC0_G1, (double)entries);
-      k_accumulate<F><<<(unsigned)((chunks0 + 255) / 256), 256, 0, st>>>(jt, (uint32_t)entries, key0, ent, off, keys1,
-                                                                         pts1, bsum, err);
-    }
-    if (chunks0 > 1) {
-      KernelTimer kt(ctx, is_g2 ? K_MSM_ACCN_G2 : K_MSM_ACCN_G1, (double)(2 * chunks0));
-      k_combine<F><<<(unsigned)(((size_t)sh.nb * COMBINE_LANES + 255) / 256), 256, 0, st>>>(
-          sh.nb, off, keys1, pts1, bsum, err + 2, (uint32_t*)(base + o_heavy));
-      // Buckets too large for k_combine exist only if some bucket spans more than LIGHT_SLOTS/2 chunks.
-      if ((size_t)max_bucket > (size_t)(LIGHT_SLOTS / 2 - 1) * ACC_K0)
-        k_heavy<F><<<256, 256, 0, st>>>(err + 2, (const uint32_t*)(base + o_heavy), off, keys1, pts1, bsum);
-    }
+  // Everything below sizes its grid for the largest possible entry count and reads the actual
+  // counts from `off` on the device, so the host never waits in the middle of a multiexp.
+  {
+    // the scalars equal to one: a plain tree sum per group, kept out of the segmented reduction
+    KernelTimer kt(ctx, is_g2 ? K_MSM_ONES_G2 : K_MSM_ONES_G1, (double)n, st);
+    k_sum_range<F><<<dim3(ones_blocks, sh.G), 256, 0, st>>>(jt, ent, off, sh.nb, ones_part, err);
+    k_sum_partials<F><<<sh.G, 256, 0, st>>>(ones_part, ones_blocks, wsum + nsets);
   }
   {
-    KernelTimer kt(ctx, is_g2 ? K_MSM_REDUCE_G2 : K_MSM_REDUCE_G1, (double)sh.nb);
+    // work units (additions actually performed) are added by msm_collect from the entry count
+    KernelTimer kt(ctx, is_g2 ? K_MSM_ACC0_G2 : K_MSM_ACC0_G1, 0.0, st);
+    k_accumulate<F><<<(unsigned)((max_chunks + 255) / 256), 256, 0, st>>>(jt, sh.nb, key0, ent, off, keys1, pts1, bsum,
+                                                                         err);
+  }
+  {
+    KernelTimer kt(ctx, is_g2 ? K_MSM_ACCN_G2 : K_MSM_ACCN_G1, (double)sh.nb, st);
+    k_combine<F><<<(unsigned)(((size_t)sh.nb * COMBINE_LANES + 255) / 256), 256, 0, st>>>(
+        sh.nb, off, keys1, pts1, bsum, err + 2, (uint32_t*)(base + o_heavy));
+    k_heavy<F><<<256, 256, 0, st>>>(err + 2, (const uint32_t*)(base + o_heavy), off, keys1, pts1, bsum);
+  }
+  {
+    KernelTimer kt(ctx, is_g2 ? K_MSM_REDUCE_G2 : K_MSM_REDUCE_G1, (double)sh.nb, st);
     k_bucket_reduce<F><<<dim3(red_blocks, nsets), 256, 0, st>>>(bsum, sh.B, part);
     k_sum_partials<F><<<nsets, 256, 0, st>>>(part, red_blocks, wsum);
   }
   ZG_HIP(ctx, hipGetLastError());
-  std::vector<XYZZ<F>> hw(nsets + 1);
-  uint32_t herr = 0;
-  ZG_HIP(ctx, hipMemcpyAsync(hw.data(), wsum, (nsets + 1) * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
-  ZG_HIP(ctx, hipMemcpyAsync(&herr, err, 4, hipMemcpyDeviceToHost, st));
-  ZG_HIP(ctx, hipStreamSynchronize(st));
-  if (herr) return fail(ctx, ZG16_ERR_UNEXPECTED_IDENTITY, "multiexp consumed a base at infinity");
-  XYZZ<F> total = XYZZ<F>::inf();
-  for (int w = (int)nsets - 1; w >= 0; w--) {
-    if (!sh.shared)
-      for (uint32_t k = 0; k < sh.c; k++) total = dbl(total);
-    add_full(total, hw[w]);
-  }
-  add_full(total, hw[nsets]);  // the scalars equal to one
-  *out_host = total;
+  ZG_HIP(ctx, hipMemcpyAsync(pinned, err, 4, hipMemcpyDeviceToHost, st));
+  ZG_HIP(ctx, hipMemcpyAsync((char*)pinned + 4, off + sh.nb, 4, hipMemcpyDeviceToHost, st));
+  ZG_HIP(ctx, hipMemcpyAsync((char*)pinned + PINNED_POINTS, wsum, (nsets + sh.G) * sizeof(XYZZ<F>),
+                             hipMemcpyDeviceToHost, st));
+  pend->nsets = nsets;
+  pend->acc_kernel = is_g2 ? K_MSM_ACC0_G2 : K_MSM_ACC0_G1;
+  pend->c = sh.c;
+  pend->shared = sh.shared;
   return ZG16_OK;
 }
 
+template <class F>
+zg16_status msm_collect(zg16_ctx* ctx, const MsmPending* pend, XYZZ<F>* out) {
+  for (uint32_t g = 0; g < pend->ngroups; g++) out[g] = XYZZ<F>::inf();
+  if (!pend->nsets) return ZG16_OK;  // no terms
+  const uint32_t* head = (const uint32_t*)pend->pinned;
+  if (head[0]) return fail(ctx, ZG16_ERR_UNEXPECTED_IDENTITY, "multiexp consumed a base at infinity");
+  if (ctx->profile) ctx->kstat[pend->acc_kernel].units += head[1];
+  const XYZZ<F>* hw = (const XYZZ<F>*)((const char*)pend->pinned + PINNED_POINTS);
+  if (pend->shared) {
+    for (uint32_t g = 0; g < pend->ngroups; g++) {
+      out[g] = hw[g];
+      add_full(out[g], hw[pend->nsets + g]);  // the scalars equal to one
+    }
+    return ZG16_OK;
+  }
+  XYZZ<F> total = XYZZ<F>::inf();
+  for (int w = (int)pend->nsets - 1; w >= 0; w--) {
+    for (uint32_t k = 0; k < pend->c; k++) total = dbl(total);
+    add_full(total, hw[w]);
+  }
+  add_full(total, hw[pend->nsets]);
+  out[0] = total;
+  return ZG16_OK;
+}
+
+template zg16_status msm_launch<Fq>(zg16_ctx*, hipStream_t, int, void*, const MsmJob<Fq>*, int, int, MsmPending*);
+template zg16_status msm_launch<Fq2>(zg16_ctx*, hipStream_t, int, void*, const MsmJob<Fq2>*, int, int, MsmPending*);
+template zg16_status msm_collect<Fq>(zg16_ctx*, const MsmPending*, XYZZ<Fq>*);
+template zg16_status msm_collect<Fq2>(zg16_ctx*, const MsmPending*, XYZZ<Fq2>*);
+
+template <class F>
+static zg16_status msm_blocking(zg16_ctx* ctx, int slot, const MsmJob<F>* jobs, int njobs, XYZZ<F>* out_host) {
+  MsmPending pend;
+  ZG_TRY(msm_launch<F>(ctx, ctx->stream, slot, ctx->pinned, jobs, njobs, 1, &pend));
+  ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return msm_collect<F>(ctx, &pend, out_host);
+}
+
 zg16_status msm_g1_device(zg16_ctx* ctx, const MsmJob<Fq>* jobs, int njobs, G1XYZZ* out_host) {
-  return msm_run<Fq>(ctx, 1, jobs, njobs, out_host);
+  return msm_blocking<Fq>(ctx, 1, jobs, njobs, out_host);
 }
 zg16_status msm_g2_device(zg16_ctx* ctx, const MsmJob<Fq2>* jobs, int njobs, G2XYZZ* out_host) {
-  return msm_run<Fq2>(ctx, 2, jobs, njobs, out_host);
+  return msm_blocking<Fq2>(ctx, 2, jobs, njobs, out_host);
 }
 
 }  // namespace zg
