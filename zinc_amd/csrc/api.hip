@@ -450,7 +450,7 @@ zg16_status zg16_prove(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1cs* r, con
 }
 
 static const char* const kKernelNames[K_COUNT] = {
-    "k_spmv_short+long", "k_ntt_pass", "k_scale_powers", "k_mul_sub_scale", "k_digits", "k_scan",
+    "k_spmv_short+long", "k_ntt_pass", "k_scale_powers", "k_mul_sub_scale", "k_sort_*+k_fine_*+k_scan_*", "k_scan",
     "k_accumulate<G1,level0>", "k_accumulate<G2,level0>", "k_accumulate<G1,level>=1>", "k_accumulate<G2,level>=1>",
     "k_bucket_reduce<G1>", "k_bucket_reduce<G2>", "k_sum_range<G1>", "k_sum_range<G2>"};
 

@@ -14,21 +14,21 @@
 //  * per-window buckets (stand-alone multiexp on caller-supplied bases): W bucket sets, host Horner.
 //
 // Pipeline (one stream, no host synchronisation until the result is read):
-//   1. k_digits<COUNT>   : Montgomery scalar -> canonical -> W signed c-bit digits; histogram
-//   2. k_scan_*          : exclusive scan of bucket sizes -> bucket offsets (+ largest bucket)
-//   3. k_digits<SCATTER> : counting sort of (bucket, window, base index, sign) entries
-//   4. k_accumulate      : segmented reduction over the sorted entries.  Every lane owns a fixed
+//   1. k_sort_* / k_fine_* : Montgomery scalar -> canonical -> W signed c-bit digits -> two-level
+//                          counting sort of the (bucket, window, base index, sign) entries
+//   2. k_scan_*          : exclusive scan of bucket sizes -> bucket offsets
+//   3. k_accumulate      : segmented reduction over the sorted entries.  Every lane owns a fixed
 //                          chunk of 64 consecutive entries whatever the bucket sizes are, so a
 //                          skewed witness (zinc witnesses are mostly 0/1 bits) cannot unbalance
 //                          the launch.  A run inside one chunk finishes its bucket; a run cut by a
 //                          chunk edge leaves a partial sum in slot 2t / 2t+1.
-//   5. k_combine         : eight lanes per bucket add that bucket's partials (buckets spanning at
+//   4. k_combine         : eight lanes per bucket add that bucket's partials (buckets spanning at
 //                          most 32 chunks) and fold by shuffles; larger buckets get one workgroup
 //                          each in k_heavy.
-//   6. k_sum_range       : plain tree sum for scalars equal to one (about half of a zinc witness);
+//   5. k_sum_range       : plain tree sum for scalars equal to one (about half of a zinc witness);
 //                          they reach their bucket through a wave-aggregated counter, not a digit.
-//   7. k_bucket_reduce   : sum_b (b+1)*S_b by segment running sums + LDS tree
-//   8. host              : Horner over the W window sums (per-window layout only)
+//   6. k_bucket_reduce   : sum_b (b+1)*S_b by segment running sums + LDS tree
+//   7. host              : Horner over the W window sums (per-window layout only)
 #define ZG_OUTLINE_FIELD_MUL 1
 #include "common.cuh"
 
@@ -98,66 +98,211 @@ ZG_D uint32_t extract_bits(const uint32_t* v, uint32_t lo, uint32_t c) {
   return (uint32_t)(x >> sh) & ((1u << c) - 1);
 }
 
-// Wave-aggregated `atomicAdd(ctr, 1)` for the lanes that call it together.
-ZG_D uint32_t wave_agg_inc(uint32_t* ctr) {
-  const unsigned long long mask = __ballot(1);
-  const int lane = threadIdx.x & 63;
-  const int leader = __ffsll((long long)mask) - 1;
-  const uint32_t rank = __popcll(mask & ((1ull << lane) - 1));
-  uint32_t base = 0;
-  if (lane == leader) base = atomicAdd(ctr, (uint32_t)__popcll(mask));
-  base = __shfl(base, leader);
-  return base + rank;
+// ---- bucket sort of the (term, window) entries --------------------------------------------------
+// An entry is 8 bytes: x = bucket | window << 24, y = term index | sign << 31.  Order inside a
+// bucket is irrelevant (group addition is exact), so this is a two-level counting sort whose global
+// atomics are per (workgroup, bin) instead of per entry:
+//   k_sort_count    terms -> digits -> LDS histogram of coarse bins (bucket >> shift, at most
+//                   SORT_MAX_COARSE of them) -> one global add per non-empty bin per workgroup
+//   k_scan_coarse   exclusive scan of the coarse bins (one workgroup)
+//   k_sort_scatter  same digits again; the workgroup reserves a run in every coarse bin with one
+//                   fetch-add and writes its entries there.  Unit scalars go straight to their final
+//                   place behind all digit entries.
+//   k_fine_count / k_fine_scatter   tiles of the coarse-sorted entries span a few coarse bins, so
+//                   their buckets are counted / ranked in LDS and again cost one global atomic per
+//                   (tile, bucket).  A tile that spans more buckets than LDS holds (tiny multiexps)
+//                   falls back to one atomic per entry.
+static constexpr uint32_t SORT_TERMS = 16;          // terms per lane in k_sort_count / k_sort_scatter
+static constexpr uint32_t SORT_MAX_COARSE = 1024;
+static constexpr uint32_t FINE_TILE = 4096;         // entries per workgroup in k_fine_*
+static constexpr uint32_t FINE_PER_LANE = FINE_TILE / 256;
+static constexpr uint32_t FINE_LDS = 8192;          // LDS counters in k_fine_*
+
+struct SortShape {
+  uint32_t shift;    // coarse bin = bucket >> shift
+  uint32_t ncoarse;  // coarse bins covering the digit buckets; bins ncoarse + g count group g's unit scalars
+};
+
+// Calls digit(bucket, window, negative) for every non-zero signed digit of term i and one(group) if
+// the scalar equals one.  Scalars equal to zero produce nothing.
+template <class F, class FD, class FO>
+ZG_D void term_digits(const JobTable<F>& jt, const MsmShape& sh, uint32_t i, FD digit, FO one) {
+  const int j = find_job(jt, i);
+  const Fr s = from_mont(load_scalar(jt, i, j));
+  uint32_t rest = 0;
+#pragma unroll
+  for (int k = 1; k < 8; k++) rest |= s.v[k];
+  if (rest == 0 && s.v[0] <= 1) {
+    if (s.v[0]) one(jt.group[j]);
+    return;
+  }
+  const uint32_t set_base = sh.shared ? jt.group[j] * sh.B : 0;
+  uint32_t carry = 0;
+  for (uint32_t w = 0; w < sh.W; w++) {
+    uint32_t d = extract_bits(s.v, w * sh.c, sh.c) + carry;
+    uint32_t neg = 0;
+    carry = 0;
+    if (d > sh.B) {
+      d = (1u << sh.c) - d;
+      neg = 1;
+      carry = 1;
+    }
+    if (d) digit(sh.shared ? set_base + d - 1 : w * sh.B + d - 1, w, neg);
+  }
 }
 
-template <class F, bool SCATTER>
-__global__ __launch_bounds__(256) void k_digits(JobTable<F> jt, MsmShape sh, uint32_t* __restrict__ hist,
-                                                uint32_t* __restrict__ cursor,
-                                                uint32_t* __restrict__ ent, uint32_t* __restrict__ keys) {
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < sh.n; i += gridDim.x * blockDim.x) {
-    const int j = find_job(jt, i);
-    const Fr s = from_mont(load_scalar(jt, i, j));
-    if (s.is_zero()) continue;
-    const uint32_t g = jt.group[j];
-    bool is_one = s.v[0] == 1;
+template <class F>
+__global__ __launch_bounds__(256) void k_sort_count(JobTable<F> jt, MsmShape sh, SortShape ss,
+                                                    uint32_t* __restrict__ chist) {
+  __shared__ uint32_t lh[SORT_MAX_COARSE + MAX_JOBS];
+  const uint32_t tid = threadIdx.x, nbins = ss.ncoarse + sh.G;
+  for (uint32_t j = tid; j < nbins; j += 256) lh[j] = 0;
+  __syncthreads();
+  const uint32_t tile = blockIdx.x * (256 * SORT_TERMS);
+  for (uint32_t k = 0; k < SORT_TERMS; k++) {
+    const uint32_t i = tile + k * 256 + tid;
+    if (i < sh.n)
+      term_digits(jt, sh, i, [&](uint32_t b, uint32_t, uint32_t) { atomicAdd(&lh[b >> ss.shift], 1u); },
+                  [&](uint32_t g) { atomicAdd(&lh[ss.ncoarse + g], 1u); });
+  }
+  __syncthreads();
+  for (uint32_t j = tid; j < nbins; j += 256)
+    if (lh[j]) atomicAdd(&chist[j], lh[j]);
+}
+
+// One workgroup: coff = exclusive scan of chist[0..nbins) (coff[nbins] = total), ccursor = copy of it,
+// and hist[nb + g] = number of unit scalars of group g so that the bucket scan places them too.
+__global__ __launch_bounds__(1024) void k_scan_coarse(const uint32_t* __restrict__ chist, uint32_t ncoarse, uint32_t G,
+                                                      uint32_t* __restrict__ coff, uint32_t* __restrict__ ccursor,
+                                                      uint32_t* __restrict__ hist, uint32_t nb) {
+  __shared__ uint32_t part[1024];
+  const uint32_t tid = threadIdx.x, nbins = ncoarse + G;
+  // nbins <= SORT_MAX_COARSE + MAX_JOBS: two counters per lane cover it
+  const uint32_t v0 = 2 * tid < nbins ? chist[2 * tid] : 0, v1 = 2 * tid + 1 < nbins ? chist[2 * tid + 1] : 0;
+  part[tid] = v0 + v1;
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024; d <<= 1) {
+    const uint32_t x = tid >= d ? part[tid - d] : 0;
+    __syncthreads();
+    part[tid] += x;
+    __syncthreads();
+  }
+  const uint32_t excl = tid ? part[tid - 1] : 0;
+  if (2 * tid < nbins) { coff[2 * tid] = excl; ccursor[2 * tid] = excl; }
+  if (2 * tid + 1 < nbins) { coff[2 * tid + 1] = excl + v0; ccursor[2 * tid + 1] = excl + v0; }
+  if (tid == 1023) coff[nbins] = part[1023];
+  if (tid < G) hist[nb + tid] = chist[ncoarse + tid];
+}
+
+template <class F>
+__global__ __launch_bounds__(256) void k_sort_scatter(JobTable<F> jt, MsmShape sh, SortShape ss,
+                                                      uint32_t* __restrict__ ccursor, uint2* __restrict__ rec_coarse,
+                                                      uint2* __restrict__ rec_final) {
+  __shared__ uint32_t lh[SORT_MAX_COARSE + MAX_JOBS];     // count, then cursor inside the reserved run
+  __shared__ uint32_t lbase[SORT_MAX_COARSE + MAX_JOBS];  // start of the run reserved in each bin
+  const uint32_t tid = threadIdx.x, nbins = ss.ncoarse + sh.G;
+  for (uint32_t j = tid; j < nbins; j += 256) lh[j] = 0;
+  __syncthreads();
+  const uint32_t tile = blockIdx.x * (256 * SORT_TERMS);
+  for (uint32_t k = 0; k < SORT_TERMS; k++) {
+    const uint32_t i = tile + k * 256 + tid;
+    if (i < sh.n)
+      term_digits(jt, sh, i, [&](uint32_t b, uint32_t, uint32_t) { atomicAdd(&lh[b >> ss.shift], 1u); },
+                  [&](uint32_t g) { atomicAdd(&lh[ss.ncoarse + g], 1u); });
+  }
+  __syncthreads();
+  for (uint32_t j = tid; j < nbins; j += 256) {
+    const uint32_t cnt = lh[j];
+    if (cnt) lbase[j] = atomicAdd(&ccursor[j], cnt);
+    lh[j] = 0;
+  }
+  __syncthreads();
+  for (uint32_t k = 0; k < SORT_TERMS; k++) {
+    const uint32_t i = tile + k * 256 + tid;
+    if (i < sh.n)
+      term_digits(
+          jt, sh, i,
+          [&](uint32_t b, uint32_t w, uint32_t neg) {
+            const uint32_t bin = b >> ss.shift;
+            const uint32_t pos = lbase[bin] + atomicAdd(&lh[bin], 1u);
+            rec_coarse[pos] = make_uint2(sh.shared ? (b | (w << 24)) : b, i | (neg << 31));
+          },
+          [&](uint32_t g) {
+            const uint32_t bin = ss.ncoarse + g;
+            const uint32_t pos = lbase[bin] + atomicAdd(&lh[bin], 1u);
+            rec_final[pos] = make_uint2(sh.nb + g, i);
+          });
+  }
+}
+
+// Bucket range [base, base + span) that the coarse-sorted tile [lo, hi) can touch.
+ZG_D void tile_span(const uint2* __restrict__ rec, uint32_t lo, uint32_t hi, uint32_t shift, uint32_t* base,
+                    uint32_t* span) {
+  const uint32_t first = (rec[lo].x & KEY_MASK) >> shift, last = (rec[hi - 1].x & KEY_MASK) >> shift;
+  *base = first << shift;
+  *span = (last - first + 1) << shift;
+}
+
+__global__ __launch_bounds__(256) void k_fine_count(const uint2* __restrict__ rec, const uint32_t* __restrict__ coff,
+                                                    SortShape ss, uint32_t* __restrict__ hist) {
+  __shared__ uint32_t lh[FINE_LDS];
+  const uint32_t tid = threadIdx.x, total = coff[ss.ncoarse];
+  const uint32_t lo = blockIdx.x * FINE_TILE;
+  if (lo >= total) return;
+  const uint32_t hi = lo + FINE_TILE < total ? lo + FINE_TILE : total;
+  uint32_t base, span;
+  tile_span(rec, lo, hi, ss.shift, &base, &span);
+  if (span > FINE_LDS) {
+    for (uint32_t i = lo + tid; i < hi; i += 256) atomicAdd(&hist[rec[i].x & KEY_MASK], 1u);
+    return;
+  }
+  for (uint32_t j = tid; j < span; j += 256) lh[j] = 0;
+  __syncthreads();
+  for (uint32_t i = lo + tid; i < hi; i += 256) atomicAdd(&lh[(rec[i].x & KEY_MASK) - base], 1u);
+  __syncthreads();
+  for (uint32_t j = tid; j < span; j += 256)
+    if (lh[j]) atomicAdd(&hist[base + j], lh[j]);
+}
+
+__global__ __launch_bounds__(256) void k_fine_scatter(const uint2* __restrict__ rec, const uint32_t* __restrict__ coff,
+                                                      SortShape ss, uint32_t* __restrict__ cursor,
+                                                      uint2* __restrict__ out) {
+  __shared__ uint32_t lh[FINE_LDS];
+  const uint32_t tid = threadIdx.x, total = coff[ss.ncoarse];
+  const uint32_t lo = blockIdx.x * FINE_TILE;
+  if (lo >= total) return;
+  const uint32_t hi = lo + FINE_TILE < total ? lo + FINE_TILE : total;
+  uint32_t base, span;
+  tile_span(rec, lo, hi, ss.shift, &base, &span);
+  if (span > FINE_LDS) {
+    for (uint32_t i = lo + tid; i < hi; i += 256) {
+      const uint2 r = rec[i];
+      out[atomicAdd(&cursor[r.x & KEY_MASK], 1u)] = r;
+    }
+    return;
+  }
+  for (uint32_t j = tid; j < span; j += 256) lh[j] = 0;
+  __syncthreads();
+  uint2 r[FINE_PER_LANE];
+  uint32_t rank[FINE_PER_LANE];
 #pragma unroll
-    for (int k = 1; k < 8; k++) is_one = is_one && s.v[k] == 0;
-    if (is_one) {
-      // lanes of one wave may belong to different groups only at a job boundary: aggregate per group
-      for (uint32_t gg = 0; gg < sh.G; gg++) {
-        if (g != gg) continue;
-        if (SCATTER) {
-          const uint32_t pos = wave_agg_inc(&cursor[sh.nb + gg]);
-          ent[pos] = i;
-          keys[pos] = sh.nb + gg;
-        } else {
-          wave_agg_inc(&hist[sh.nb + gg]);
-        }
-      }
-      continue;
+  for (uint32_t k = 0; k < FINE_PER_LANE; k++) {
+    const uint32_t i = lo + k * 256 + tid;
+    if (i < hi) {
+      r[k] = rec[i];
+      rank[k] = atomicAdd(&lh[(r[k].x & KEY_MASK) - base], 1u);
     }
-    const uint32_t set_base = sh.shared ? g * sh.B : 0;
-    uint32_t carry = 0;
-    for (uint32_t w = 0; w < sh.W; w++) {
-      uint32_t d = extract_bits(s.v, w * sh.c, sh.c) + carry;
-      uint32_t neg = 0;
-      carry = 0;
-      if (d > sh.B) {
-        d = (1u << sh.c) - d;
-        neg = 1;
-        carry = 1;
-      }
-      if (d) {
-        const uint32_t bucket = sh.shared ? set_base + d - 1 : w * sh.B + d - 1;
-        if (SCATTER) {
-          const uint32_t pos = atomicAdd(&cursor[bucket], 1u);
-          ent[pos] = i | (neg << 31);
-          keys[pos] = sh.shared ? (bucket | (w << 24)) : bucket;
-        } else {
-          atomicAdd(&hist[bucket], 1u);
-        }
-      }
-    }
+  }
+  __syncthreads();
+  for (uint32_t j = tid; j < span; j += 256) {
+    const uint32_t cnt = lh[j];
+    if (cnt) lh[j] = atomicAdd(&cursor[base + j], cnt);  // the counter becomes the start of this tile's run
+  }
+  __syncthreads();
+#pragma unroll
+  for (uint32_t k = 0; k < FINE_PER_LANE; k++) {
+    const uint32_t i = lo + k * 256 + tid;
+    if (i < hi) out[lh[(r[k].x & KEY_MASK) - base] + rank[k]] = r[k];
   }
 }
 
@@ -241,8 +386,7 @@ ZG_D bool bucket_is_light(uint32_t s, uint32_t e) {
 // leaves a partial sum in slot 2t (first run) or 2t+1 (last run) for k_combine / k_heavy.
 template <class F>
 __global__ __launch_bounds__(256, kMinWaves<F>) void k_accumulate(JobTable<F> jt, uint32_t nb,
-                                                                  const uint32_t* __restrict__ keys_in,
-                                                                  const uint32_t* __restrict__ ent_in,
+                                                                  const uint2* __restrict__ rec,
                                                                   const uint32_t* __restrict__ off,
                                                                   uint32_t* __restrict__ keys_out,
                                                                   XYZZ<F>* __restrict__ pts_out,
@@ -271,14 +415,14 @@ __global__ __launch_bounds__(256, kMinWaves<F>) void k_accumulate(JobTable<F> jt
   };
 
   for (uint32_t i = lo; i < hi; i++) {
-    const uint32_t kw = keys_in[i];
+    const uint2 rc = rec[i];
+    const uint32_t kw = rc.x, e = rc.y;
     const uint32_t k = kw & KEY_MASK;
     if (k != cur) {
       if (cur != KEY_INVALID) flush();
       cur = k;
       acc = XYZZ<F>::inf();
     }
-    const uint32_t e = ent_in[i];
     Affine<F> p = load_base(jt, e & 0x7fffffffu, kw >> 24);
     if (p.is_inf()) *err_flag = 1;  // identity base consumed by a non-zero scalar
     if (e >> 31) p.y = neg(p.y);
@@ -432,10 +576,10 @@ __global__ __launch_bounds__(256, kMinWaves<F>) void k_sum_partials(const XYZZ<F
 }
 
 // Plain sum of the bases whose scalar equals one, group blockIdx.y: the entries are
-// ent[off[nb+g] .. off[nb+g+1]).  Each lane adds a contiguous share, the workgroup tree-adds, one
+// rec[off[nb+g] .. off[nb+g+1]).  Each lane adds a contiguous share, the workgroup tree-adds, one
 // partial per workgroup at part[g * gridDim.x + blockIdx.x].
 template <class F>
-__global__ __launch_bounds__(256, kMinWaves<F>) void k_sum_range(JobTable<F> jt, const uint32_t* __restrict__ ent,
+__global__ __launch_bounds__(256, kMinWaves<F>) void k_sum_range(JobTable<F> jt, const uint2* __restrict__ rec,
                                                                    const uint32_t* __restrict__ off, uint32_t nb,
                                                                    XYZZ<F>* __restrict__ part,
                                                                    uint32_t* __restrict__ err_flag) {
@@ -448,7 +592,7 @@ __global__ __launch_bounds__(256, kMinWaves<F>) void k_sum_range(JobTable<F> jt,
   const uint32_t b = a + per < hi ? a + per : hi;
   XYZZ<F> acc = XYZZ<F>::inf();
   for (uint32_t i = a; i < b; i++) {
-    const Affine<F> p = load_base(jt, ent[i] & 0x7fffffffu, 0);
+    const Affine<F> p = load_base(jt, rec[i].y & 0x7fffffffu, 0);
     if (p.is_inf()) *err_flag = 1;
     add_mixed(acc, p);
   }
@@ -569,15 +713,25 @@ zg16_status msm_launch(zg16_ctx* ctx, hipStream_t st, int scratch_slot, void* pi
     return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "multiexp result block too large");
   const uint32_t ncount = sh.nb + sh.G;  // counters: digit buckets, then one unit-scalar bucket per group
 
+  SortShape ss;
+  ss.shift = 7;
+  while (((sh.nb + (1u << ss.shift) - 1) >> ss.shift) > SORT_MAX_COARSE) ss.shift++;
+  ss.ncoarse = (sh.nb + (1u << ss.shift) - 1) >> ss.shift;
+  const uint32_t nbins = ss.ncoarse + sh.G;
+
   // scratch layout
   auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
   size_t o = 0;
   const size_t o_hist = o;   o += align((size_t)ncount * 4);
   const size_t o_off = o;    o += align((size_t)(ncount + 1) * 4);
   const size_t o_cur = o;    o += align((size_t)ncount * 4);
+  const size_t o_chist = o;  o += align((size_t)nbins * 4);
+  const size_t o_coff = o;   o += align((size_t)(nbins + 1) * 4);
+  const size_t o_ccur = o;   o += align((size_t)nbins * 4);
   const size_t o_err = o;    o += 256;  // [0] identity-base flag, [2] number of heavy buckets
-  const size_t o_ent = o;    o += align(max_entries * 4);
-  const size_t o_key0 = o;   o += align(max_entries * 4);
+  const size_t o_zero_end = o;
+  const size_t o_rec0 = o;   o += align(max_entries * sizeof(uint2));  // coarse-sorted entries
+  const size_t o_rec = o;    o += align(max_entries * sizeof(uint2));  // bucket-sorted entries
   const size_t max_chunks = (max_entries + ACC_K0 - 1) / ACC_K0;
   const size_t o_keys1 = o;  o += align(2 * max_chunks * 4);
   const size_t o_pts1 = o;   o += align(2 * max_chunks * sizeof(XYZZ<F>));
@@ -595,9 +749,12 @@ zg16_status msm_launch(zg16_ctx* ctx, hipStream_t st, int scratch_slot, void* pi
   uint32_t* hist = (uint32_t*)(base + o_hist);
   uint32_t* off = (uint32_t*)(base + o_off);
   uint32_t* cursor = (uint32_t*)(base + o_cur);
+  uint32_t* chist = (uint32_t*)(base + o_chist);
+  uint32_t* coff = (uint32_t*)(base + o_coff);
+  uint32_t* ccursor = (uint32_t*)(base + o_ccur);
   uint32_t* err = (uint32_t*)(base + o_err);
-  uint32_t* ent = (uint32_t*)(base + o_ent);
-  uint32_t* key0 = (uint32_t*)(base + o_key0);
+  uint2* rec0 = (uint2*)(base + o_rec0);
+  uint2* rec = (uint2*)(base + o_rec);
   uint32_t* keys1 = (uint32_t*)(base + o_keys1);
   XYZZ<F>* pts1 = (XYZZ<F>*)(base + o_pts1);
   XYZZ<F>* bsum = (XYZZ<F>*)(base + o_bsum);
@@ -606,37 +763,34 @@ zg16_status msm_launch(zg16_ctx* ctx, hipStream_t st, int scratch_slot, void* pi
   XYZZ<F>* part = (XYZZ<F>*)(base + o_part);
   XYZZ<F>* ones_part = part + (size_t)nsets * red_blocks;
 
-  ZG_HIP(ctx, hipMemsetAsync(base, 0, o_ent, st));  // hist, off, cursor, err
+  ZG_HIP(ctx, hipMemsetAsync(base, 0, o_zero_end, st));  // every counter and flag
   ZG_HIP(ctx, hipMemsetAsync(bsum, 0, (size_t)sh.nb * sizeof(XYZZ<F>), st));
-  const unsigned dgrid = (unsigned)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256);
   constexpr bool is_g2 = sizeof(F) > sizeof(Fq);
   {
     KernelTimer kt(ctx, K_MSM_DIGITS, (double)n, st);
-    k_digits<F, false><<<dgrid, 256, 0, st>>>(jt, sh, hist, cursor, ent, key0);
-  }
-  {
-    KernelTimer kt(ctx, K_MSM_SCAN, (double)ncount, st);
+    const unsigned sgrid = (unsigned)((n + 256 * SORT_TERMS - 1) / (256 * SORT_TERMS));
+    const unsigned fgrid = (unsigned)((max_entries + FINE_TILE - 1) / FINE_TILE);
+    k_sort_count<F><<<sgrid, 256, 0, st>>>(jt, sh, ss, chist);
+    k_scan_coarse<<<1, 1024, 0, st>>>(chist, ss.ncoarse, sh.G, coff, ccursor, hist, sh.nb);
+    k_sort_scatter<F><<<sgrid, 256, 0, st>>>(jt, sh, ss, ccursor, rec0, rec);
+    k_fine_count<<<fgrid, 256, 0, st>>>(rec0, coff, ss, hist);
     k_scan_local<<<ntiles, 256, 0, st>>>(hist, ncount, off, tiles);
     k_scan_tiles<<<1, 1024, 0, st>>>(tiles, ntiles);
     k_scan_fixup<<<(ncount + 1 + 255) / 256, 256, 0, st>>>(off, cursor, ncount, tiles, ntiles);
-  }
-  {
-    KernelTimer kt(ctx, K_MSM_DIGITS, (double)n, st);
-    k_digits<F, true><<<dgrid, 256, 0, st>>>(jt, sh, hist, cursor, ent, key0);
+    k_fine_scatter<<<fgrid, 256, 0, st>>>(rec0, coff, ss, cursor, rec);
   }
   // Everything below sizes its grid for the largest possible entry count and reads the actual
   // counts from `off` on the device, so the host never waits in the middle of a multiexp.
   {
     // the scalars equal to one: a plain tree sum per group, kept out of the segmented reduction
     KernelTimer kt(ctx, is_g2 ? K_MSM_ONES_G2 : K_MSM_ONES_G1, (double)n, st);
-    k_sum_range<F><<<dim3(ones_blocks, sh.G), 256, 0, st>>>(jt, ent, off, sh.nb, ones_part, err);
+    k_sum_range<F><<<dim3(ones_blocks, sh.G), 256, 0, st>>>(jt, rec, off, sh.nb, ones_part, err);
     k_sum_partials<F><<<sh.G, 256, 0, st>>>(ones_part, ones_blocks, wsum + nsets);
   }
   {
     // work units (additions actually performed) are added by msm_collect from the entry count
     KernelTimer kt(ctx, is_g2 ? K_MSM_ACC0_G2 : K_MSM_ACC0_G1, 0.0, st);
-    k_accumulate<F><<<(unsigned)((max_chunks + 255) / 256), 256, 0, st>>>(jt, sh.nb, key0, ent, off, keys1, pts1, bsum,
-                                                                         err);
+    k_accumulate<F><<<(unsigned)((max_chunks + 255) / 256), 256, 0, st>>>(jt, sh.nb, rec, off, keys1, pts1, bsum, err);
   }
   {
     KernelTimer kt(ctx, is_g2 ? K_MSM_ACCN_G2 : K_MSM_ACCN_G1, (double)sh.nb, st);
