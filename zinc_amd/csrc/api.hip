@@ -122,6 +122,14 @@ zg16_status zg16_ctx_create(int device_id, zg16_ctx** out) {
     return ZG16_ERR_DEVICE;
   }
   ctx->stream = ctx->own_stream;
+  for (auto& ss : ctx->side_stream)
+    if (hipStreamCreateWithFlags(&ss, hipStreamNonBlocking) != hipSuccess) {
+      delete ctx;
+      return ZG16_ERR_DEVICE;
+    }
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0)
+    ctx->cu_count = cus;
   if (hipHostMalloc(&ctx->pinned, 2 * MSM_PINNED_BYTES, hipHostMallocDefault) != hipSuccess) {
     delete ctx;
     return ZG16_ERR_DEVICE;
@@ -146,6 +154,8 @@ void zg16_ctx_destroy(zg16_ctx* ctx) {
     if (e) (void)hipEventDestroy(e);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
+  for (auto& ss : ctx->side_stream)
+    if (ss) (void)hipStreamDestroy(ss);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   delete ctx;
 }
@@ -322,7 +332,8 @@ zg16_status zg16_prove_partial(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1cs
     ZG_HIP(ctx, hipStreamWaitEvent(aux, ev[E_Z], 0));
     ZG_HIP(ctx, hipEventRecord(ev[E_G2_BEGIN], aux));
     MsmJob<Fq2> jb = {pk->b2, z, r->b_map + pk->lo_b, pk->hi_b - pk->lo_b, stride(pk->lo_b, pk->hi_b), tc, 0};
-    ZG_TRY(msm_launch<Fq2>(ctx, aux, 2, (char*)ctx->pinned + MSM_PINNED_BYTES, &jb, 1, 1, &pend_g2));
+    const MsmStreams ms = {aux, ctx->side_stream[1], ev[10], ev[11]};
+    ZG_TRY(msm_launch<Fq2>(ctx, ms, 2, (char*)ctx->pinned + MSM_PINNED_BYTES, &jb, 1, 1, &pend_g2));
     ZG_HIP(ctx, hipEventRecord(ev[E_G2_END], aux));
   }
 
@@ -344,7 +355,8 @@ zg16_status zg16_prove_partial(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1cs
         {pk->a, z, r->a_map + pk->lo_a, pk->hi_a - pk->lo_a, stride(pk->lo_a, pk->hi_a), tc, 1},
         {pk->b1, z, r->b_map + pk->lo_b, pk->hi_b - pk->lo_b, stride(pk->lo_b, pk->hi_b), tc, 2}};
     if (tc) {
-      ZG_TRY(msm_launch<Fq>(ctx, st, 1, ctx->pinned, jobs, 4, 3, &pend_g1));
+      const MsmStreams ms = {st, ctx->side_stream[0], ev[8], ev[9]};
+      ZG_TRY(msm_launch<Fq>(ctx, ms, 1, ctx->pinned, jobs, 4, 3, &pend_g1));
       ZG_HIP(ctx, hipEventRecord(ev[E_G1], st));
       ZG_HIP(ctx, hipStreamWaitEvent(st, ev[E_G2_END], 0));
       ZG_HIP(ctx, hipEventRecord(ev[E_END], st));

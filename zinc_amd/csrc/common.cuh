@@ -42,7 +42,9 @@ struct zg16_ctx {
   std::vector<hipEvent_t> event_pool;
   hipStream_t stream = nullptr;      // stream all kernels are issued on
   hipStream_t own_stream = nullptr;  // created by the context
-  hipStream_t aux_stream = nullptr;  // second stream for overlapping independent stages
+  hipStream_t aux_stream = nullptr;  // second stream: the G2 multiexp runs beside everything else
+  hipStream_t side_stream[2] = {};   // short side branches of the two multiexp pipelines
+  int cu_count = 256;
   void* pinned = nullptr;            // page-locked host memory for asynchronous result read-backs
   hipEvent_t ev[12] = {};
   std::string last_error = "";
@@ -184,8 +186,8 @@ zg16_status msm_g1_device(zg16_ctx* ctx, const MsmJob<Fq>* jobs, int njobs, G1XY
 zg16_status msm_g2_device(zg16_ctx* ctx, const MsmJob<Fq2>* jobs, int njobs, G2XYZZ* out_host);
 
 // Asynchronous form, so that several multiexps can be in flight on different streams.  msm_launch
-// enqueues every kernel of the multiexp on `st` plus a copy of the results into `pinned`
-// (MSM_PINNED_BYTES of page-locked host memory) and returns without waiting; once `st` is idle
+// enqueues every kernel of the multiexp on `ms.main` plus a copy of the results into `pinned`
+// (MSM_PINNED_BYTES of page-locked host memory) and returns without waiting; once `ms.main` is idle
 // msm_collect turns the block into `ngroups` points.  Jobs of one launch may form several groups
 // (independent sums) only when every job brings a window table of the same width.
 static constexpr size_t MSM_PINNED_BYTES = 32768;
@@ -194,9 +196,14 @@ struct MsmPending {
   uint32_t nsets = 0, ngroups = 0, c = 0, shared = 0;
   int acc_kernel = 0;  // KernelId whose work units (additions) are known only after the run
 };
+struct MsmStreams {
+  hipStream_t main;
+  hipStream_t side;             // optional: the unit-scalar sums run here beside the bucket pipeline
+  hipEvent_t ev_fork, ev_join;  // used when side is set
+};
 template <class F>
-zg16_status msm_launch(zg16_ctx* ctx, hipStream_t st, int scratch_slot, void* pinned, const MsmJob<F>* jobs, int njobs,
-                       int ngroups, MsmPending* pend);
+zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, void* pinned, const MsmJob<F>* jobs,
+                       int njobs, int ngroups, MsmPending* pend);
 template <class F>
 zg16_status msm_collect(zg16_ctx* ctx, const MsmPending* pend, XYZZ<F>* out);
 

@@ -34,8 +34,8 @@
 
 namespace zg {
 
-static constexpr int ACC_K0 = 64;     // entries per lane at level 0
-static constexpr int LIGHT_SLOTS = 64;  // buckets whose partials span at most this many slots: k_combine
+static constexpr uint32_t ACC_KMIN = 8;   // fewest entries a lane of k_accumulate takes
+static constexpr int LIGHT_SLOTS = 64;    // buckets whose partials span at most this many slots: k_combine
 static constexpr int MAX_JOBS = 4;
 static constexpr uint32_t KEY_INVALID = 0xffffffffu;
 static constexpr uint32_t KEY_MASK = 0x00ffffffu;  // level-0 keys carry the window in the top byte
@@ -376,35 +376,44 @@ __global__ __launch_bounds__(256) void k_scan_fixup(uint32_t* __restrict__ off, 
   }
 }
 
-// k_combine owns the buckets whose partial slots span at most LIGHT_SLOTS; k_heavy owns the rest.
-ZG_D bool bucket_is_light(uint32_t s, uint32_t e) {
-  return 2 * ((e - 1) / ACC_K0 - s / ACC_K0 + 1) <= (uint32_t)LIGHT_SLOTS;
+// Entries per lane of k_accumulate: the launch has a fixed number of lanes (sized to fill the GPU
+// once) and the sorted entries are dealt out evenly, so the chunk length follows the entry count.
+ZG_D uint32_t chunk_len(uint32_t entries, uint32_t lanes) {
+  const uint32_t k = (entries + lanes - 1) / lanes;
+  return k < ACC_KMIN ? ACC_KMIN : k;
 }
 
-// Level 0 of the segmented reduction (the grid covers the largest possible entry count; the actual
-// one is read from off[nb]): lane t owns sorted entries [64t, 64t+64) whatever the bucket sizes are.  A run that lies inside the chunk finishes its bucket; a run cut by a chunk edge
-// leaves a partial sum in slot 2t (first run) or 2t+1 (last run) for k_combine / k_heavy.
+// k_combine owns the buckets whose partial slots span at most LIGHT_SLOTS; k_heavy owns the rest.
+ZG_D bool bucket_is_light(uint32_t s, uint32_t e, uint32_t K) {
+  return 2 * ((e - 1) / K - s / K + 1) <= (uint32_t)LIGHT_SLOTS;
+}
+
+// Level 0 of the segmented reduction: lane t owns sorted entries [K t, K t + K) whatever the bucket
+// sizes are (K = chunk_len of the entry count off[nb], read on the device).  A run that lies inside
+// the chunk finishes its bucket; a run cut by a chunk edge leaves a partial sum in slot 2t (first
+// run) or 2t+1 (last run) for k_combine / k_heavy.
 template <class F>
-__global__ __launch_bounds__(256, kMinWaves<F>) void k_accumulate(JobTable<F> jt, uint32_t nb,
+__global__ __launch_bounds__(256, kMinWaves<F>) void k_accumulate(JobTable<F> jt, uint32_t nb, uint32_t lanes,
                                                                   const uint2* __restrict__ rec,
                                                                   const uint32_t* __restrict__ off,
                                                                   uint32_t* __restrict__ keys_out,
                                                                   XYZZ<F>* __restrict__ pts_out,
                                                                   XYZZ<F>* __restrict__ bucket_sum,
                                                                   uint32_t* __restrict__ err_flag) {
-  constexpr uint32_t K = ACC_K0;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t lo = t * K;
   const uint32_t nslots = off[nb];  // digit entries; the unit-scalar entries behind them go to k_sum_range
-  if (lo >= nslots) return;
-  const uint32_t hi = lo + K < nslots ? lo + K : nslots;
+  const uint32_t K = chunk_len(nslots, lanes);
+  const uint64_t lo64 = (uint64_t)t * K;
+  if (lo64 >= nslots) return;
+  const uint32_t lo = (uint32_t)lo64;
+  const uint32_t hi = nslots - lo > K ? lo + K : nslots;
   uint32_t cur = KEY_INVALID;
   XYZZ<F> acc = XYZZ<F>::inf();
   bool first_run = true;
   uint32_t out_key[2] = {KEY_INVALID, KEY_INVALID};
 
   auto flush = [&]() {
-    if (off[cur] >= lo && off[cur + 1] <= lo + K) {
+    if (off[cur] >= lo && off[cur + 1] <= hi) {
       bucket_sum[cur] = acc;
     } else {
       const int slot = first_run ? 0 : 1;  // a cut run is the first or (otherwise) the last of its chunk
@@ -443,28 +452,29 @@ ZG_D XYZZ<F> shfl_down_point(const XYZZ<F>& p, int d) {
   return o;
 }
 
-// COMBINE_LANES lanes per bucket add the partial sums level 0 left for a bucket it cut into a few
-// pieces, then fold across the lanes by shuffles.  Buckets spanning more than LIGHT_SLOTS slots are
-// appended to heavy_list for k_heavy.
-static constexpr int COMBINE_LANES = 8;
-template <class F>
-__global__ __launch_bounds__(256, kMinWaves<F>) void k_combine(uint32_t nb, const uint32_t* __restrict__ off,
+// L adjacent lanes per bucket add the partial sums level 0 left for a bucket it cut into a few
+// pieces (one valid partial per chunk the bucket touches), then fold across the lanes by shuffles.
+// Buckets spanning more than LIGHT_SLOTS slots are appended to heavy_list for k_heavy.
+template <class F, int L>
+__global__ __launch_bounds__(256, kMinWaves<F>) void k_combine(uint32_t nb, uint32_t lanes,
+                                                                 const uint32_t* __restrict__ off,
                                                                  const uint32_t* __restrict__ keys1,
                                                                  const XYZZ<F>* __restrict__ pts1,
                                                                  XYZZ<F>* __restrict__ bucket_sum,
                                                                  uint32_t* __restrict__ heavy_count,
                                                                  uint32_t* __restrict__ heavy_list) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t b = t / COMBINE_LANES, sub = t % COMBINE_LANES;
+  const uint32_t b = t / L, sub = t % L;
+  const uint32_t K = chunk_len(off[nb], lanes);
   uint32_t lo = 0, hi = 0;  // slot range this bucket's lanes share; empty when there is nothing to add
   if (b < nb) {
     const uint32_t s = off[b], e = off[b + 1];
     if (e > s) {
-      const uint32_t cf = s / ACC_K0, cl = (e - 1) / ACC_K0;
+      const uint32_t cf = s / K, cl = (e - 1) / K;
       if (cf != cl) {  // otherwise level 0 finished it inside one chunk
-        if (bucket_is_light(s, e)) {
+        if (bucket_is_light(s, e, K)) {
           lo = 2 * cf;
-          hi = 2 * cl + 2;
+          hi = 2 * cl + 1;  // in its last chunk the bucket is the first run: head slot
         } else if (sub == 0) {
           heavy_list[atomicAdd(heavy_count, 1u)] = b;
         }
@@ -472,13 +482,15 @@ __global__ __launch_bounds__(256, kMinWaves<F>) void k_combine(uint32_t nb, cons
     }
   }
   XYZZ<F> acc = XYZZ<F>::inf();
-  for (uint32_t i = lo + sub; i < hi; i += COMBINE_LANES)
+  for (uint32_t i = lo + sub; i < hi; i += L)
     if (keys1[i] == b) add_full(acc, pts1[i]);
-  // the lanes of one bucket are adjacent in the wave and all of them reach this point
-  if (__ballot(hi > lo) != 0) {
-    for (int d = COMBINE_LANES / 2; d >= 1; d >>= 1) {
-      const XYZZ<F> o = shfl_down_point(acc, d);
-      if (sub + d < COMBINE_LANES) add_full(acc, o);
+  if (L > 1) {
+    // the lanes of one bucket are adjacent in the wave and all of them reach this point
+    if (__ballot(hi > lo) != 0) {
+      for (int d = L / 2; d >= 1; d >>= 1) {
+        const XYZZ<F> o = shfl_down_point(acc, d);
+        if (sub + d < L) add_full(acc, o);
+      }
     }
   }
   if (hi > lo && sub == 0) bucket_sum[b] = acc;
@@ -489,8 +501,8 @@ __global__ __launch_bounds__(256, kMinWaves<F>) void k_combine(uint32_t nb, cons
 template <class F>
 __global__ __launch_bounds__(256, kMinWaves<F>) void k_heavy(const uint32_t* __restrict__ heavy_count,
                                                                const uint32_t* __restrict__ heavy_list,
-                                                               const uint32_t* __restrict__ off,
-                                                               const uint32_t* __restrict__ keys1,
+                                                               const uint32_t* __restrict__ off, uint32_t nb,
+                                                               uint32_t lanes, const uint32_t* __restrict__ keys1,
                                                                const XYZZ<F>* __restrict__ pts1,
                                                                XYZZ<F>* __restrict__ bucket_sum);
 
@@ -520,16 +532,17 @@ ZG_D void block_sum(XYZZ<F>& total, XYZZ<F>* sh /* [128] */) {
 template <class F>
 __global__ __launch_bounds__(256, kMinWaves<F>) void k_heavy(const uint32_t* __restrict__ heavy_count,
                                                                const uint32_t* __restrict__ heavy_list,
-                                                               const uint32_t* __restrict__ off,
-                                                               const uint32_t* __restrict__ keys1,
+                                                               const uint32_t* __restrict__ off, uint32_t nb,
+                                                               uint32_t lanes, const uint32_t* __restrict__ keys1,
                                                                const XYZZ<F>* __restrict__ pts1,
                                                                XYZZ<F>* __restrict__ bucket_sum) {
   __shared__ XYZZ<F> sh[128];
   const uint32_t n = *heavy_count;
+  const uint32_t K = chunk_len(off[nb], lanes);
   for (uint32_t h = blockIdx.x; h < n; h += gridDim.x) {
     const uint32_t b = heavy_list[h];
     const uint32_t s = off[b], e = off[b + 1];
-    const uint32_t lo = 2 * (s / ACC_K0), hi = 2 * ((e - 1) / ACC_K0) + 2;
+    const uint32_t lo = 2 * (s / K), hi = 2 * ((e - 1) / K) + 1;
     XYZZ<F> acc = XYZZ<F>::inf();
     for (uint32_t i = lo + threadIdx.x; i < hi; i += 256)
       if (keys1[i] == b) add_full(acc, pts1[i]);
@@ -663,8 +676,9 @@ template zg16_status msm_build_table<Fq2>(zg16_ctx*, Affine<Fq2>*, size_t, uint3
 static constexpr size_t PINNED_POINTS = 256;
 
 template <class F>
-zg16_status msm_launch(zg16_ctx* ctx, hipStream_t st, int scratch_slot, void* pinned, const MsmJob<F>* jobs, int njobs,
-                       int ngroups, MsmPending* pend) {
+zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, void* pinned, const MsmJob<F>* jobs,
+                       int njobs, int ngroups, MsmPending* pend) {
+  hipStream_t st = ms.main;
   if (njobs > MAX_JOBS) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "too many multiexp jobs");
   if (ngroups < 1 || ngroups > MAX_JOBS) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "bad multiexp group count");
   JobTable<F> jt = {};
@@ -732,9 +746,12 @@ zg16_status msm_launch(zg16_ctx* ctx, hipStream_t st, int scratch_slot, void* pi
   const size_t o_zero_end = o;
   const size_t o_rec0 = o;   o += align(max_entries * sizeof(uint2));  // coarse-sorted entries
   const size_t o_rec = o;    o += align(max_entries * sizeof(uint2));  // bucket-sorted entries
-  const size_t max_chunks = (max_entries + ACC_K0 - 1) / ACC_K0;
-  const size_t o_keys1 = o;  o += align(2 * max_chunks * 4);
-  const size_t o_pts1 = o;   o += align(2 * max_chunks * sizeof(XYZZ<F>));
+  // k_accumulate runs a fixed number of lanes: one full round of the GPU at the occupancy its
+  // registers allow (G1 four waves per SIMD, G2 one; G2 gets two rounds so that its chunks stay short).
+  constexpr bool is_g2 = sizeof(F) > sizeof(Fq);
+  const uint32_t lanes = (uint32_t)ctx->cu_count * 4 * 64 * (is_g2 ? 2 : 4);
+  const size_t o_keys1 = o;  o += align(2 * (size_t)lanes * 4);
+  const size_t o_pts1 = o;   o += align(2 * (size_t)lanes * sizeof(XYZZ<F>));
   const size_t o_heavy = o;  o += align((size_t)sh.nb * 4);
   const size_t o_bsum = o;   o += align((size_t)sh.nb * sizeof(XYZZ<F>));
   const size_t o_wsum = o;   o += align((size_t)(nsets + sh.G) * sizeof(XYZZ<F>));
@@ -765,7 +782,6 @@ zg16_status msm_launch(zg16_ctx* ctx, hipStream_t st, int scratch_slot, void* pi
 
   ZG_HIP(ctx, hipMemsetAsync(base, 0, o_zero_end, st));  // every counter and flag
   ZG_HIP(ctx, hipMemsetAsync(bsum, 0, (size_t)sh.nb * sizeof(XYZZ<F>), st));
-  constexpr bool is_g2 = sizeof(F) > sizeof(Fq);
   {
     KernelTimer kt(ctx, K_MSM_DIGITS, (double)n, st);
     const unsigned sgrid = (unsigned)((n + 256 * SORT_TERMS - 1) / (256 * SORT_TERMS));
@@ -782,21 +798,31 @@ zg16_status msm_launch(zg16_ctx* ctx, hipStream_t st, int scratch_slot, void* pi
   // Everything below sizes its grid for the largest possible entry count and reads the actual
   // counts from `off` on the device, so the host never waits in the middle of a multiexp.
   {
-    // the scalars equal to one: a plain tree sum per group, kept out of the segmented reduction
-    KernelTimer kt(ctx, is_g2 ? K_MSM_ONES_G2 : K_MSM_ONES_G1, (double)n, st);
-    k_sum_range<F><<<dim3(ones_blocks, sh.G), 256, 0, st>>>(jt, rec, off, sh.nb, ones_part, err);
-    k_sum_partials<F><<<sh.G, 256, 0, st>>>(ones_part, ones_blocks, wsum + nsets);
+    // The scalars equal to one: a plain tree sum per group, kept out of the segmented reduction.  It
+    // depends only on the sort, so it runs on the side stream beside the bucket pipeline when there is one.
+    hipStream_t so = ms.side ? ms.side : st;
+    if (ms.side) {
+      ZG_HIP(ctx, hipEventRecord(ms.ev_fork, st));
+      ZG_HIP(ctx, hipStreamWaitEvent(so, ms.ev_fork, 0));
+    }
+    {
+      KernelTimer kt(ctx, is_g2 ? K_MSM_ONES_G2 : K_MSM_ONES_G1, (double)n, so);
+      k_sum_range<F><<<dim3(ones_blocks, sh.G), 256, 0, so>>>(jt, rec, off, sh.nb, ones_part, err);
+      k_sum_partials<F><<<sh.G, 256, 0, so>>>(ones_part, ones_blocks, wsum + nsets);
+    }
+    if (ms.side) ZG_HIP(ctx, hipEventRecord(ms.ev_join, so));
   }
   {
     // work units (additions actually performed) are added by msm_collect from the entry count
     KernelTimer kt(ctx, is_g2 ? K_MSM_ACC0_G2 : K_MSM_ACC0_G1, 0.0, st);
-    k_accumulate<F><<<(unsigned)((max_chunks + 255) / 256), 256, 0, st>>>(jt, sh.nb, rec, off, keys1, pts1, bsum, err);
+    k_accumulate<F><<<lanes / 256, 256, 0, st>>>(jt, sh.nb, lanes, rec, off, keys1, pts1, bsum, err);
   }
   {
     KernelTimer kt(ctx, is_g2 ? K_MSM_ACCN_G2 : K_MSM_ACCN_G1, (double)sh.nb, st);
-    k_combine<F><<<(unsigned)(((size_t)sh.nb * COMBINE_LANES + 255) / 256), 256, 0, st>>>(
-        sh.nb, off, keys1, pts1, bsum, err + 2, (uint32_t*)(base + o_heavy));
-    k_heavy<F><<<256, 256, 0, st>>>(err + 2, (const uint32_t*)(base + o_heavy), off, keys1, pts1, bsum);
+    constexpr int L = 2;
+    k_combine<F, L><<<(unsigned)(((size_t)sh.nb * L + 255) / 256), 256, 0, st>>>(
+        sh.nb, lanes, off, keys1, pts1, bsum, err + 2, (uint32_t*)(base + o_heavy));
+    k_heavy<F><<<256, 256, 0, st>>>(err + 2, (const uint32_t*)(base + o_heavy), off, sh.nb, lanes, keys1, pts1, bsum);
   }
   {
     KernelTimer kt(ctx, is_g2 ? K_MSM_REDUCE_G2 : K_MSM_REDUCE_G1, (double)sh.nb, st);
@@ -804,6 +830,7 @@ zg16_status msm_launch(zg16_ctx* ctx, hipStream_t st, int scratch_slot, void* pi
     k_sum_partials<F><<<nsets, 256, 0, st>>>(part, red_blocks, wsum);
   }
   ZG_HIP(ctx, hipGetLastError());
+  if (ms.side) ZG_HIP(ctx, hipStreamWaitEvent(st, ms.ev_join, 0));
   ZG_HIP(ctx, hipMemcpyAsync(pinned, err, 4, hipMemcpyDeviceToHost, st));
   ZG_HIP(ctx, hipMemcpyAsync((char*)pinned + 4, off + sh.nb, 4, hipMemcpyDeviceToHost, st));
   ZG_HIP(ctx, hipMemcpyAsync((char*)pinned + PINNED_POINTS, wsum, (nsets + sh.G) * sizeof(XYZZ<F>),
@@ -840,15 +867,16 @@ zg16_status msm_collect(zg16_ctx* ctx, const MsmPending* pend, XYZZ<F>* out) {
   return ZG16_OK;
 }
 
-template zg16_status msm_launch<Fq>(zg16_ctx*, hipStream_t, int, void*, const MsmJob<Fq>*, int, int, MsmPending*);
-template zg16_status msm_launch<Fq2>(zg16_ctx*, hipStream_t, int, void*, const MsmJob<Fq2>*, int, int, MsmPending*);
+template zg16_status msm_launch<Fq>(zg16_ctx*, const MsmStreams&, int, void*, const MsmJob<Fq>*, int, int, MsmPending*);
+template zg16_status msm_launch<Fq2>(zg16_ctx*, const MsmStreams&, int, void*, const MsmJob<Fq2>*, int, int, MsmPending*);
 template zg16_status msm_collect<Fq>(zg16_ctx*, const MsmPending*, XYZZ<Fq>*);
 template zg16_status msm_collect<Fq2>(zg16_ctx*, const MsmPending*, XYZZ<Fq2>*);
 
 template <class F>
 static zg16_status msm_blocking(zg16_ctx* ctx, int slot, const MsmJob<F>* jobs, int njobs, XYZZ<F>* out_host) {
   MsmPending pend;
-  ZG_TRY(msm_launch<F>(ctx, ctx->stream, slot, ctx->pinned, jobs, njobs, 1, &pend));
+  MsmStreams ms = {ctx->stream, nullptr, nullptr, nullptr};
+  ZG_TRY(msm_launch<F>(ctx, ms, slot, ctx->pinned, jobs, njobs, 1, &pend));
   ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return msm_collect<F>(ctx, &pend, out_host);
 }
