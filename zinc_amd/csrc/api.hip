@@ -28,7 +28,8 @@ zg16_status upload_query(zg16_ctx* ctx, Affine<F>** dst, const void* src, size_t
   const size_t windows = table_c ? msm_table_windows(table_c) : 1;
   ZG_HIP(ctx, hipMalloc((void**)dst, windows * count * sizeof(Affine<F>)));
   ZG_HIP(ctx, hipMemcpy(*dst, src, count * sizeof(Affine<F>), hipMemcpyHostToDevice));
-  if (table_c) ZG_TRY(msm_build_table<F>(ctx, *dst, count, table_c));
+  // fills the other windows (if any) and rewrites every point in the multiexp kernels' packed form
+  ZG_TRY(msm_build_table<F>(ctx, *dst, count, table_c));
   return ZG16_OK;
 }
 
@@ -96,7 +97,7 @@ zg16_status msm_entry(zg16_ctx* ctx, const uint64_t* bases, size_t n_bases, cons
   if (n_bases) ZG_HIP(ctx, hipMemcpyAsync(d_b, bases, b_bytes, hipMemcpyHostToDevice, ctx->stream));
   if (n_scalars) ZG_HIP(ctx, hipMemcpyAsync(d_s, scalars, s_bytes, hipMemcpyHostToDevice, ctx->stream));
   if (m_bytes) ZG_HIP(ctx, hipMemcpyAsync(d_m, map.data(), m_bytes, hipMemcpyHostToDevice, ctx->stream));
-  ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ZG_TRY(msm_build_table<F>(ctx, d_b, n_bases, 0));  // bases -> the multiexp kernels' packed form
   MsmJob<F> job = {d_b, d_s, density ? d_m : nullptr, n_bases, 0, 0, 0};
   XYZZ<F> res;
   ZG_TRY(run(ctx, &job, 1, &res));

@@ -1,0 +1,143 @@
+// BN254 G1 group operations over the 29-bit-limb field of fp29.cuh (device only).
+//
+// Same formulas as curve.cuh (extended Jacobian XYZZ: madd-2008-s, add-2008-s, dbl-2008-s-1), with
+// the value bounds of the lazy field written next to each step in units of p:
+//   stored points:  X < 8p,  Y < 5p,  ZZ, ZZZ < 2p,  limbs normalised;  ZZ == 0 (all limbs) <=> identity
+//   affine bases:   x, y < p canonical
+// Every product keeps (bound of a) * (bound of b) <= 169, which is what makes its result < 2p.
+// Exact group results do not depend on any of this: the affine point is the one bellman_ce computes
+// (reached from zinc-vm/src/core/circuit/facade.rs:153).
+#pragma once
+#include "curve.cuh"
+#include "fp29.cuh"
+
+namespace zg {
+
+template <class P>
+struct Affine29 {
+  Fp29<P> x, y;
+};
+
+template <class P>
+struct XYZZ29 {
+  Fp29<P> x, y, zz, zzz;
+  ZG_D bool is_inf() const { return zz.is_zero_limbs(); }
+  ZG_D static XYZZ29 inf() { return {Fp29<P>::zero(), Fp29<P>::zero(), Fp29<P>::zero(), Fp29<P>::zero()}; }
+};
+
+// 2*(x, y) for an affine, non-identity input
+template <class P>
+ZG_D XYZZ29<P> dbl_affine29(const Affine29<P>& p) {
+  using F = Fp29<P>;
+  const F u = mul_small_k(p.y, 2);                    // 2
+  const F v = sqr(u);                                 // <2
+  const F w = mul(u, v);                              // <2
+  const F s = mul(p.x, v);                            // <2
+  const F m = mul_small_k(sqr(p.x), 3);               // <6
+  const F x3 = sub2_k(sqr(m), F::zero(), s, P::K6);   // m^2 - 2s : < 2 + 6 = 8
+  const F t = sub_k(s, x3, P::K8);                    // < 2 + 8 = 10
+  const F y3 = sub_k(mul(m, t), mul(w, p.y), P::K3);  // < 2 + 3 = 5
+  return {x3, y3, v, w};
+}
+
+template <class P>
+ZG_D XYZZ29<P> dbl29(const XYZZ29<P>& p) {
+  using F = Fp29<P>;
+  if (p.is_inf()) return p;
+  const F u = mul_small_k(p.y, 2);                    // <10
+  const F v = sqr(u);                                 // 100 -> <2
+  const F w = mul(u, v);                              // <2
+  const F s = mul(p.x, v);                            // 16 -> <2
+  const F m = mul_small_k(sqr(p.x), 3);               // 64 -> <2, times 3: <6
+  const F x3 = sub2_k(sqr(m), F::zero(), s, P::K6);   // <8
+  const F t = sub_k(s, x3, P::K8);                    // <10
+  const F y3 = sub_k(mul(m, t), mul(w, p.y), P::K3);  // 60, 10 -> <5
+  return {x3, y3, mul(v, p.zz), mul(w, p.zzz)};
+}
+
+// acc += p (affine, not the identity)
+template <class P>
+ZG_D void add_mixed29(XYZZ29<P>& acc, const Affine29<P>& p) {
+  using F = Fp29<P>;
+  if (acc.is_inf()) {
+    acc = {p.x, p.y, F::one(), F::one()};
+    return;
+  }
+  const F u2 = mul(p.x, acc.zz);                  // <2
+  const F s2 = mul(p.y, acc.zzz);                 // <2
+  const F pp_ = sub_k(u2, acc.x, P::K8);          // <10
+  const F pp = sqr(pp_);                          // <2
+  if (is_zero_mod_p(pp)) {                        // same x: doubling or cancellation (rare)
+    const F r0 = sub_k(s2, acc.y, P::K6);
+    const F rr = sqr(r0);
+    if (is_zero_mod_p(rr))
+      acc = dbl_affine29(p);
+    else
+      acc = XYZZ29<P>::inf();
+    return;
+  }
+  const F r = sub_k(s2, acc.y, P::K6);            // <8
+  const F ppp = mul(pp_, pp);                     // <2
+  const F q = mul(acc.x, pp);                     // <2
+  const F x3 = sub2_k(sqr(r), ppp, q, P::K6);     // r^2 - ppp - 2q : < 2 + 6 = 8
+  const F t = sub_k(q, x3, P::K8);                // <10
+  const F y3 = sub_k(mul(r, t), mul(acc.y, ppp), P::K3);  // 80, 10 -> < 5
+  acc.x = x3;
+  acc.y = y3;
+  acc.zz = mul(acc.zz, pp);
+  acc.zzz = mul(acc.zzz, ppp);
+}
+
+// acc += p (XYZZ)
+template <class P>
+ZG_D void add_full29(XYZZ29<P>& acc, const XYZZ29<P>& p) {
+  using F = Fp29<P>;
+  if (p.is_inf()) return;
+  if (acc.is_inf()) {
+    acc = p;
+    return;
+  }
+  const F u1 = mul(acc.x, p.zz);                  // 16 -> <2
+  const F u2 = mul(p.x, acc.zz);
+  const F s1 = mul(acc.y, p.zzz);
+  const F s2 = mul(p.y, acc.zzz);
+  const F pp_ = sub_k(u2, u1, P::K3);             // <5
+  const F pp = sqr(pp_);
+  if (is_zero_mod_p(pp)) {
+    const F r0 = sub_k(s2, s1, P::K3);
+    if (is_zero_mod_p(sqr(r0)))
+      acc = dbl29(acc);
+    else
+      acc = XYZZ29<P>::inf();
+    return;
+  }
+  const F r = sub_k(s2, s1, P::K3);               // <5
+  const F ppp = mul(pp_, pp);
+  const F q = mul(u1, pp);
+  const F x3 = sub2_k(sqr(r), ppp, q, P::K6);     // <8
+  const F t = sub_k(q, x3, P::K8);                // <10
+  const F y3 = sub_k(mul(r, t), mul(s1, ppp), P::K3);  // <5
+  acc.x = x3;
+  acc.y = y3;
+  acc.zz = mul(mul(acc.zz, p.zz), pp);
+  acc.zzz = mul(mul(acc.zzz, p.zzz), ppp);
+}
+
+// ---- memory formats -------------------------------------------------------------------------
+// Packed affine base (x || y, 8 x 32-bit words each, canonical, radix-2^261 Montgomery form).
+template <class P, class Q>
+ZG_D Affine29<P> unpack_affine(const Affine<Fp<Q>>& a) {
+  return {unpack29<P>(a.x), unpack29<P>(a.y)};
+}
+
+// XYZZ29 -> the library's XYZZ<Fq> (radix-2^256 Montgomery form, canonical), e.g. for the host.
+template <class P, class Q>
+ZG_D XYZZ<Fp<Q>> export_xyzz(const XYZZ29<P>& p) {
+  if (p.is_inf()) return XYZZ<Fp<Q>>::inf();
+  return {to_r256<P, Q>(p.x), to_r256<P, Q>(p.y), to_r256<P, Q>(p.zz), to_r256<P, Q>(p.zzz)};
+}
+
+using G1Affine29 = Affine29<Fq29Params>;
+using G1XYZZ29 = XYZZ29<Fq29Params>;
+
+}  // namespace zg

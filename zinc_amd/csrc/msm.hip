@@ -31,6 +31,7 @@
 //   7. host              : Horner over the W window sums (per-window layout only)
 #define ZG_OUTLINE_FIELD_MUL 1
 #include "common.cuh"
+#include "msm_ops.cuh"
 
 namespace zg {
 
@@ -41,10 +42,9 @@ static constexpr uint32_t KEY_INVALID = 0xffffffffu;
 static constexpr uint32_t KEY_MASK = 0x00ffffffu;  // level-0 keys carry the window in the top byte
 static constexpr int RED_SEG = 8;     // buckets per lane in the window reduction
 
-// Minimum waves per SIMD requested from the register allocator for the curve kernels: a G1 lane
-// keeps ~100 live dwords (XYZZ accumulator, base, temporaries), a G2 lane twice that.
+// Minimum waves per SIMD requested from the register allocator for the curve kernels.
 template <class F>
-constexpr int kMinWaves = sizeof(F) > 32 ? 1 : 4;
+constexpr int kMinWaves = MsmOps<F>::MIN_WAVES;
 
 template <class F>
 struct JobTable {
@@ -83,11 +83,11 @@ ZG_D Fr load_scalar(const JobTable<F>& jt, uint32_t i, int j) {
   return jt.scalars[j][si];
 }
 
-// base of term i for window w (w = 0 when the buckets are per-window)
+// address of the base of term i for window w (w = 0 when the buckets are per-window)
 template <class F>
-ZG_D Affine<F> load_base(const JobTable<F>& jt, uint32_t i, uint32_t w) {
+ZG_D const Affine<F>* base_ptr(const JobTable<F>& jt, uint32_t i, uint32_t w) {
   const int j = find_job(jt, i);
-  return jt.bases[j][(size_t)w * jt.stride[j] + (i - jt.start[j])];
+  return jt.bases[j] + ((size_t)w * jt.stride[j] + (i - jt.start[j]));
 }
 
 // bits [lo, lo+c) of a 256-bit little-endian integer (c <= 24)
@@ -388,19 +388,20 @@ ZG_D bool bucket_is_light(uint32_t s, uint32_t e, uint32_t K) {
   return 2 * ((e - 1) / K - s / K + 1) <= (uint32_t)LIGHT_SLOTS;
 }
 
-// Level 0 of the segmented reduction: lane t owns sorted entries [K t, K t + K) whatever the bucket
-// sizes are (K = chunk_len of the entry count off[nb], read on the device).  A run that lies inside
-// the chunk finishes its bucket; a run cut by a chunk edge leaves a partial sum in slot 2t (first
-// run) or 2t+1 (last run) for k_combine / k_heavy.
+// Level 0 of the segmented reduction: logical thread t owns sorted entries [K t, K t + K) whatever
+// the bucket sizes are (K = chunk_len of the entry count off[nb], read on the device).  A run that
+// lies inside the chunk finishes its bucket; a run cut by a chunk edge leaves a partial sum in slot
+// 2t (first run) or 2t+1 (last run) for k_combine / k_heavy.
 template <class F>
 __global__ __launch_bounds__(256, kMinWaves<F>) void k_accumulate(JobTable<F> jt, uint32_t nb, uint32_t lanes,
                                                                   const uint2* __restrict__ rec,
                                                                   const uint32_t* __restrict__ off,
                                                                   uint32_t* __restrict__ keys_out,
-                                                                  XYZZ<F>* __restrict__ pts_out,
-                                                                  XYZZ<F>* __restrict__ bucket_sum,
+                                                                  typename MsmOps<F>::PtMem* __restrict__ pts_out,
+                                                                  typename MsmOps<F>::PtMem* __restrict__ bucket_sum,
                                                                   uint32_t* __restrict__ err_flag) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  using O = MsmOps<F>;
+  const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) / O::LP;
   const uint32_t nslots = off[nb];  // digit entries; the unit-scalar entries behind them go to k_sum_range
   const uint32_t K = chunk_len(nslots, lanes);
   const uint64_t lo64 = (uint64_t)t * K;
@@ -408,17 +409,17 @@ __global__ __launch_bounds__(256, kMinWaves<F>) void k_accumulate(JobTable<F> jt
   const uint32_t lo = (uint32_t)lo64;
   const uint32_t hi = nslots - lo > K ? lo + K : nslots;
   uint32_t cur = KEY_INVALID;
-  XYZZ<F> acc = XYZZ<F>::inf();
+  typename O::Pt acc = O::inf();
   bool first_run = true;
   uint32_t out_key[2] = {KEY_INVALID, KEY_INVALID};
 
   auto flush = [&]() {
     if (off[cur] >= lo && off[cur + 1] <= hi) {
-      bucket_sum[cur] = acc;
+      O::store(bucket_sum + cur, acc);
     } else {
       const int slot = first_run ? 0 : 1;  // a cut run is the first or (otherwise) the last of its chunk
       out_key[slot] = cur;
-      pts_out[2 * (size_t)t + slot] = acc;
+      O::store(pts_out + (2 * (size_t)t + slot), acc);
     }
     first_run = false;
   };
@@ -430,43 +431,37 @@ __global__ __launch_bounds__(256, kMinWaves<F>) void k_accumulate(JobTable<F> jt
     if (k != cur) {
       if (cur != KEY_INVALID) flush();
       cur = k;
-      acc = XYZZ<F>::inf();
+      acc = O::inf();
     }
-    Affine<F> p = load_base(jt, e & 0x7fffffffu, kw >> 24);
-    if (p.is_inf()) *err_flag = 1;  // identity base consumed by a non-zero scalar
-    if (e >> 31) p.y = neg(p.y);
-    add_mixed(acc, p);
+    typename O::Aff p;
+    if (O::load_base(base_ptr(jt, e & 0x7fffffffu, kw >> 24), (e >> 31) != 0, &p))
+      O::madd(acc, p);
+    else
+      *err_flag = 1;  // identity base consumed by a non-zero scalar
   }
   if (cur != KEY_INVALID) flush();
-  keys_out[2 * (size_t)t] = out_key[0];
-  keys_out[2 * (size_t)t + 1] = out_key[1];
+  if ((threadIdx.x % O::LP) == 0) {
+    keys_out[2 * (size_t)t] = out_key[0];
+    keys_out[2 * (size_t)t + 1] = out_key[1];
+  }
 }
 
-template <class F>
-ZG_D XYZZ<F> shfl_down_point(const XYZZ<F>& p, int d) {
-  XYZZ<F> o;
-  const uint32_t* src = (const uint32_t*)&p;
-  uint32_t* dst = (uint32_t*)&o;
-#pragma unroll
-  for (int i = 0; i < (int)(sizeof(XYZZ<F>) / 4); i++) dst[i] = __shfl_down(src[i], d);
-  return o;
-}
-
-// L adjacent lanes per bucket add the partial sums level 0 left for a bucket it cut into a few
-// pieces (one valid partial per chunk the bucket touches), then fold across the lanes by shuffles.
-// Buckets spanning more than LIGHT_SLOTS slots are appended to heavy_list for k_heavy.
+// L adjacent logical threads per bucket add the partial sums level 0 left for a bucket it cut into a
+// few pieces (one valid partial per chunk the bucket touches), then fold across the threads by
+// shuffles.  Buckets spanning more than LIGHT_SLOTS slots are appended to heavy_list for k_heavy.
 template <class F, int L>
 __global__ __launch_bounds__(256, kMinWaves<F>) void k_combine(uint32_t nb, uint32_t lanes,
                                                                  const uint32_t* __restrict__ off,
                                                                  const uint32_t* __restrict__ keys1,
-                                                                 const XYZZ<F>* __restrict__ pts1,
-                                                                 XYZZ<F>* __restrict__ bucket_sum,
+                                                                 const typename MsmOps<F>::PtMem* __restrict__ pts1,
+                                                                 typename MsmOps<F>::PtMem* __restrict__ bucket_sum,
                                                                  uint32_t* __restrict__ heavy_count,
                                                                  uint32_t* __restrict__ heavy_list) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  using O = MsmOps<F>;
+  const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) / O::LP;
   const uint32_t b = t / L, sub = t % L;
   const uint32_t K = chunk_len(off[nb], lanes);
-  uint32_t lo = 0, hi = 0;  // slot range this bucket's lanes share; empty when there is nothing to add
+  uint32_t lo = 0, hi = 0;  // slot range this bucket's threads share; empty when there is nothing to add
   if (b < nb) {
     const uint32_t s = off[b], e = off[b + 1];
     if (e > s) {
@@ -475,154 +470,169 @@ __global__ __launch_bounds__(256, kMinWaves<F>) void k_combine(uint32_t nb, uint
         if (bucket_is_light(s, e, K)) {
           lo = 2 * cf;
           hi = 2 * cl + 1;  // in its last chunk the bucket is the first run: head slot
-        } else if (sub == 0) {
+        } else if (sub == 0 && (threadIdx.x % O::LP) == 0) {
           heavy_list[atomicAdd(heavy_count, 1u)] = b;
         }
       }
     }
   }
-  XYZZ<F> acc = XYZZ<F>::inf();
+  typename O::Pt acc = O::inf();
   for (uint32_t i = lo + sub; i < hi; i += L)
-    if (keys1[i] == b) add_full(acc, pts1[i]);
+    if (keys1[i] == b) O::add(acc, O::load(pts1 + i));
   if (L > 1) {
-    // the lanes of one bucket are adjacent in the wave and all of them reach this point
+    // the threads of one bucket are adjacent in the wave and all of them reach this point
     if (__ballot(hi > lo) != 0) {
       for (int d = L / 2; d >= 1; d >>= 1) {
-        const XYZZ<F> o = shfl_down_point(acc, d);
-        if (sub + d < L) add_full(acc, o);
+        const typename O::Pt o = O::shfl_down(acc, d * O::LP);
+        if (sub + d < L) O::add(acc, o);
       }
     }
   }
-  if (hi > lo && sub == 0) bucket_sum[b] = acc;
+  if (hi > lo && sub == 0) O::store(bucket_sum + b, acc);
 }
-
-// One workgroup per heavy bucket (grid-stride over heavy_list): lanes stride over the bucket's
-// partial slots, then the workgroup tree-adds through LDS.
-template <class F>
-__global__ __launch_bounds__(256, kMinWaves<F>) void k_heavy(const uint32_t* __restrict__ heavy_count,
-                                                               const uint32_t* __restrict__ heavy_list,
-                                                               const uint32_t* __restrict__ off, uint32_t nb,
-                                                               uint32_t lanes, const uint32_t* __restrict__ keys1,
-                                                               const XYZZ<F>* __restrict__ pts1,
-                                                               XYZZ<F>* __restrict__ bucket_sum);
 
 // p * k for a small unsigned k
 template <class F>
-ZG_D XYZZ<F> mul_small(const XYZZ<F>& p, uint32_t k) {
-  XYZZ<F> acc = XYZZ<F>::inf();
+ZG_D typename MsmOps<F>::Pt mul_small(const typename MsmOps<F>::Pt& p, uint32_t k) {
+  using O = MsmOps<F>;
+  typename O::Pt acc = O::inf();
   for (int b = 31 - __clz(k | 1); b >= 0; b--) {
-    acc = dbl(acc);
-    if ((k >> b) & 1) add_full(acc, p);
+    acc = O::dbl(acc);
+    if ((k >> b) & 1) O::add(acc, p);
   }
   return acc;
 }
 
-// Workgroup tree sum through LDS; the result is valid in thread 0.
+// Workgroup tree sum through LDS (256 lanes = 256 / LP logical threads); the result is valid in
+// logical thread 0.  sh holds 128 lanes' worth of points.
 template <class F>
-ZG_D void block_sum(XYZZ<F>& total, XYZZ<F>* sh /* [128] */) {
+ZG_D void block_sum(typename MsmOps<F>::Pt& total, typename MsmOps<F>::Pt* sh /* [128] */) {
+  using O = MsmOps<F>;
   const uint32_t tid = threadIdx.x;
-  for (uint32_t stride = 128; stride >= 1; stride >>= 1) {
+  for (uint32_t stride = 128; stride >= (uint32_t)O::LP; stride >>= 1) {
     if (tid >= stride && tid < 2 * stride) sh[tid - stride] = total;
     __syncthreads();
-    if (tid < stride) add_full(total, sh[tid]);
+    if (tid < stride) O::add(total, sh[tid]);
     __syncthreads();
   }
 }
 
+// One workgroup per heavy bucket (grid-stride over heavy_list): logical threads stride over the
+// bucket's partial slots, then the workgroup tree-adds through LDS.
 template <class F>
 __global__ __launch_bounds__(256, kMinWaves<F>) void k_heavy(const uint32_t* __restrict__ heavy_count,
                                                                const uint32_t* __restrict__ heavy_list,
                                                                const uint32_t* __restrict__ off, uint32_t nb,
                                                                uint32_t lanes, const uint32_t* __restrict__ keys1,
-                                                               const XYZZ<F>* __restrict__ pts1,
-                                                               XYZZ<F>* __restrict__ bucket_sum) {
-  __shared__ XYZZ<F> sh[128];
+                                                               const typename MsmOps<F>::PtMem* __restrict__ pts1,
+                                                               typename MsmOps<F>::PtMem* __restrict__ bucket_sum) {
+  using O = MsmOps<F>;
+  __shared__ typename O::Pt sh[128];
   const uint32_t n = *heavy_count;
   const uint32_t K = chunk_len(off[nb], lanes);
+  const uint32_t lt = threadIdx.x / O::LP, nlt = 256 / O::LP;
   for (uint32_t h = blockIdx.x; h < n; h += gridDim.x) {
     const uint32_t b = heavy_list[h];
     const uint32_t s = off[b], e = off[b + 1];
     const uint32_t lo = 2 * (s / K), hi = 2 * ((e - 1) / K) + 1;
-    XYZZ<F> acc = XYZZ<F>::inf();
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += 256)
-      if (keys1[i] == b) add_full(acc, pts1[i]);
-    block_sum(acc, sh);
-    if (threadIdx.x == 0) bucket_sum[b] = acc;
+    typename O::Pt acc = O::inf();
+    for (uint32_t i = lo + lt; i < hi; i += nlt)
+      if (keys1[i] == b) O::add(acc, O::load(pts1 + i));
+    block_sum<F>(acc, sh);
+    if (lt == 0) O::store(bucket_sum + b, acc);
   }
 }
 
 // Bucket-set sums, stage 1: part[w][blk] = sum over this workgroup's buckets of (b+1) * S[w*B + b].
-// Grid (blocks per set, sets).  A lane folds RED_SEG consecutive buckets by running sums and adds
-// seg_start * (segment sum); the workgroup then tree-adds through LDS.
+// Grid (blocks per set, sets).  A logical thread folds RED_SEG consecutive buckets by running sums
+// and adds seg_start * (segment sum); the workgroup then tree-adds through LDS.
 template <class F>
-__global__ __launch_bounds__(256, kMinWaves<F>) void k_bucket_reduce(const XYZZ<F>* __restrict__ bucket_sum, uint32_t B,
-                                                       XYZZ<F>* __restrict__ part) {
-  __shared__ XYZZ<F> sh[128];
-  const uint32_t w = blockIdx.y, tid = threadIdx.x;
-  const XYZZ<F>* S = bucket_sum + (size_t)w * B;
-  const uint32_t seg = (blockIdx.x * 256 + tid) * RED_SEG;
-  XYZZ<F> acc = XYZZ<F>::inf();
+__global__ __launch_bounds__(256, kMinWaves<F>) void k_bucket_reduce(const typename MsmOps<F>::PtMem* __restrict__ bucket_sum,
+                                                                       uint32_t B,
+                                                                       typename MsmOps<F>::PtMem* __restrict__ part) {
+  using O = MsmOps<F>;
+  __shared__ typename O::Pt sh[128];
+  const uint32_t w = blockIdx.y, lt = threadIdx.x / O::LP, nlt = 256 / O::LP;
+  const typename O::PtMem* S = bucket_sum + (size_t)w * B;
+  const uint32_t seg = (blockIdx.x * nlt + lt) * RED_SEG;
+  typename O::Pt acc = O::inf();
   if (seg < B) {
     const uint32_t hi = seg + RED_SEG < B ? seg + RED_SEG : B;
-    XYZZ<F> run = XYZZ<F>::inf();
+    typename O::Pt run = O::inf();
     for (uint32_t b = hi; b-- > seg;) {
-      add_full(run, S[b]);
-      add_full(acc, run);
+      O::add(run, O::load(S + b));
+      O::add(acc, run);
     }
     // acc = sum (b - seg + 1) S_b ; add seg * run
-    if (seg) add_full(acc, mul_small(run, seg));
+    if (seg) O::add(acc, mul_small<F>(run, seg));
   }
-  block_sum(acc, sh);
-  if (tid == 0) part[(size_t)w * gridDim.x + blockIdx.x] = acc;
+  block_sum<F>(acc, sh);
+  if (lt == 0) O::store(part + ((size_t)w * gridDim.x + blockIdx.x), acc);
 }
 
 // out[w] = sum of part[w][0..count).  One workgroup per w.
 template <class F>
-__global__ __launch_bounds__(256, kMinWaves<F>) void k_sum_partials(const XYZZ<F>* __restrict__ part, uint32_t count,
-                                                      XYZZ<F>* __restrict__ out) {
-  __shared__ XYZZ<F> sh[128];
-  const uint32_t w = blockIdx.x, tid = threadIdx.x;
-  XYZZ<F> acc = XYZZ<F>::inf();
-  for (uint32_t i = tid; i < count; i += 256) add_full(acc, part[(size_t)w * count + i]);
-  block_sum(acc, sh);
-  if (tid == 0) out[w] = acc;
+__global__ __launch_bounds__(256, kMinWaves<F>) void k_sum_partials(const typename MsmOps<F>::PtMem* __restrict__ part,
+                                                                      uint32_t count,
+                                                                      typename MsmOps<F>::PtMem* __restrict__ out) {
+  using O = MsmOps<F>;
+  __shared__ typename O::Pt sh[128];
+  const uint32_t w = blockIdx.x, lt = threadIdx.x / O::LP, nlt = 256 / O::LP;
+  typename O::Pt acc = O::inf();
+  for (uint32_t i = lt; i < count; i += nlt) O::add(acc, O::load(part + ((size_t)w * count + i)));
+  block_sum<F>(acc, sh);
+  if (lt == 0) O::store(out + w, acc);
 }
 
 // Plain sum of the bases whose scalar equals one, group blockIdx.y: the entries are
-// rec[off[nb+g] .. off[nb+g+1]).  Each lane adds a contiguous share, the workgroup tree-adds, one
-// partial per workgroup at part[g * gridDim.x + blockIdx.x].
+// rec[off[nb+g] .. off[nb+g+1]).  Each logical thread adds a contiguous share, the workgroup
+// tree-adds, one partial per workgroup at part[g * gridDim.x + blockIdx.x].
 template <class F>
 __global__ __launch_bounds__(256, kMinWaves<F>) void k_sum_range(JobTable<F> jt, const uint2* __restrict__ rec,
                                                                    const uint32_t* __restrict__ off, uint32_t nb,
-                                                                   XYZZ<F>* __restrict__ part,
+                                                                   typename MsmOps<F>::PtMem* __restrict__ part,
                                                                    uint32_t* __restrict__ err_flag) {
-  __shared__ XYZZ<F> sh[128];
-  const uint32_t g = blockIdx.y;
+  using O = MsmOps<F>;
+  __shared__ typename O::Pt sh[128];
+  const uint32_t g = blockIdx.y, lt = threadIdx.x / O::LP, nlt = 256 / O::LP;
   const uint32_t lo = off[nb + g], hi = off[nb + g + 1];
-  const uint32_t nthreads = gridDim.x * 256, t = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t nthreads = gridDim.x * nlt, t = blockIdx.x * nlt + lt;
   const uint32_t per = (hi - lo + nthreads - 1) / nthreads;
   const uint32_t a = lo + t * per < hi ? lo + t * per : hi;
   const uint32_t b = a + per < hi ? a + per : hi;
-  XYZZ<F> acc = XYZZ<F>::inf();
+  typename O::Pt acc = O::inf();
   for (uint32_t i = a; i < b; i++) {
-    const Affine<F> p = load_base(jt, rec[i].y & 0x7fffffffu, 0);
-    if (p.is_inf()) *err_flag = 1;
-    add_mixed(acc, p);
+    typename O::Aff p;
+    if (O::load_base(base_ptr(jt, rec[i].y & 0x7fffffffu, 0), false, &p))
+      O::madd(acc, p);
+    else
+      *err_flag = 1;
   }
-  block_sum(acc, sh);
-  if (threadIdx.x == 0) part[(size_t)g * gridDim.x + blockIdx.x] = acc;
+  block_sum<F>(acc, sh);
+  if (lt == 0) O::store(part + ((size_t)g * gridDim.x + blockIdx.x), acc);
 }
 
-// table[w*stride + i] = 2^(c*w) * table[i] for w in 1..W-1 (window 0 is already in place).
+// Results for the host: the library-wide XYZZ form.
 template <class F>
-__global__ __launch_bounds__(256, kMinWaves<F>) void k_build_table(Affine<F>* __restrict__ table, uint32_t n, uint32_t stride,
-                                                     uint32_t W, uint32_t c) {
+__global__ void k_export(const typename MsmOps<F>::PtMem* __restrict__ in, uint32_t count, XYZZ<F>* __restrict__ out) {
+  using O = MsmOps<F>;
+  const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) / O::LP;
+  if (t < count) O::store_std(out + t, O::load(in + t));
+}
+
+// table[w*stride + i] = 2^(c*w) * table[i] for w in 1..W-1, every window in the internal packed form
+// (window 0 arrives in the ABI form and is rewritten).  W = 1 just converts the points.
+template <class F>
+__global__ __launch_bounds__(256, 1) void k_build_table(Affine<F>* __restrict__ table, uint32_t n, uint32_t stride,
+                                                        uint32_t W, uint32_t c) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  XYZZ<F> acc = XYZZ<F>::from_affine(table[i]);
+  const Affine<F> p0 = table[i];
+  table[i] = MsmOps<F>::to_internal(p0);
+  XYZZ<F> acc = XYZZ<F>::from_affine(p0);
   for (uint32_t w = 1; w < W; w++) {
     for (uint32_t k = 0; k < c; k++) acc = dbl(acc);
-    table[(size_t)w * stride + i] = to_affine(acc);
+    table[(size_t)w * stride + i] = MsmOps<F>::to_internal(to_affine(acc));
   }
 }
 
@@ -664,7 +674,7 @@ template <class F>
 zg16_status msm_build_table(zg16_ctx* ctx, Affine<F>* table, size_t n, uint32_t c) {
   if (!n) return ZG16_OK;
   k_build_table<F><<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(table, (uint32_t)n, (uint32_t)n,
-                                                                        msm_table_windows(c), c);
+                                                                        c ? msm_table_windows(c) : 1, c);
   ZG_HIP(ctx, hipGetLastError());
   ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return ZG16_OK;
@@ -751,16 +761,18 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
   constexpr bool is_g2 = sizeof(F) > sizeof(Fq);
   const uint32_t lanes = (uint32_t)ctx->cu_count * 4 * 64 * (is_g2 ? 2 : 4);
   const size_t o_keys1 = o;  o += align(2 * (size_t)lanes * 4);
-  const size_t o_pts1 = o;   o += align(2 * (size_t)lanes * sizeof(XYZZ<F>));
+  using PtMem = typename MsmOps<F>::PtMem;
+  const size_t o_pts1 = o;   o += align(2 * (size_t)lanes * sizeof(PtMem));
   const size_t o_heavy = o;  o += align((size_t)sh.nb * 4);
-  const size_t o_bsum = o;   o += align((size_t)sh.nb * sizeof(XYZZ<F>));
-  const size_t o_wsum = o;   o += align((size_t)(nsets + sh.G) * sizeof(XYZZ<F>));
+  const size_t o_bsum = o;   o += align((size_t)sh.nb * sizeof(PtMem));
+  const size_t o_wsum = o;   o += align((size_t)(nsets + sh.G) * sizeof(PtMem));
+  const size_t o_wstd = o;   o += align((size_t)(nsets + sh.G) * sizeof(XYZZ<F>));  // the same for the host
   const uint32_t ntiles = (ncount + SCAN_TILE - 1) / SCAN_TILE;
   const uint32_t red_blocks = (sh.B + 256 * RED_SEG - 1) / (256 * RED_SEG);
   uint32_t ones_blocks = (uint32_t)((n + 256 * 16 - 1) / (256 * 16));
   if (ones_blocks > 1024) ones_blocks = 1024;
   const size_t o_tiles = o;  o += align((size_t)(ntiles + 1) * 4);
-  const size_t o_part = o;   o += align((size_t)(nsets * red_blocks + sh.G * ones_blocks) * sizeof(XYZZ<F>));
+  const size_t o_part = o;   o += align((size_t)(nsets * red_blocks + sh.G * ones_blocks) * sizeof(PtMem));
   char* base;
   ZG_TRY(scratch_get(ctx, scratch_slot, o, (void**)&base));
   uint32_t* hist = (uint32_t*)(base + o_hist);
@@ -773,15 +785,16 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
   uint2* rec0 = (uint2*)(base + o_rec0);
   uint2* rec = (uint2*)(base + o_rec);
   uint32_t* keys1 = (uint32_t*)(base + o_keys1);
-  XYZZ<F>* pts1 = (XYZZ<F>*)(base + o_pts1);
-  XYZZ<F>* bsum = (XYZZ<F>*)(base + o_bsum);
-  XYZZ<F>* wsum = (XYZZ<F>*)(base + o_wsum);
+  PtMem* pts1 = (PtMem*)(base + o_pts1);
+  PtMem* bsum = (PtMem*)(base + o_bsum);
+  PtMem* wsum = (PtMem*)(base + o_wsum);
+  XYZZ<F>* wstd = (XYZZ<F>*)(base + o_wstd);
   uint32_t* tiles = (uint32_t*)(base + o_tiles);
-  XYZZ<F>* part = (XYZZ<F>*)(base + o_part);
-  XYZZ<F>* ones_part = part + (size_t)nsets * red_blocks;
+  PtMem* part = (PtMem*)(base + o_part);
+  PtMem* ones_part = part + (size_t)nsets * red_blocks;
 
   ZG_HIP(ctx, hipMemsetAsync(base, 0, o_zero_end, st));  // every counter and flag
-  ZG_HIP(ctx, hipMemsetAsync(bsum, 0, (size_t)sh.nb * sizeof(XYZZ<F>), st));
+  ZG_HIP(ctx, hipMemsetAsync(bsum, 0, (size_t)sh.nb * sizeof(PtMem), st));
   {
     KernelTimer kt(ctx, K_MSM_DIGITS, (double)n, st);
     const unsigned sgrid = (unsigned)((n + 256 * SORT_TERMS - 1) / (256 * SORT_TERMS));
@@ -833,7 +846,9 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
   if (ms.side) ZG_HIP(ctx, hipStreamWaitEvent(st, ms.ev_join, 0));
   ZG_HIP(ctx, hipMemcpyAsync(pinned, err, 4, hipMemcpyDeviceToHost, st));
   ZG_HIP(ctx, hipMemcpyAsync((char*)pinned + 4, off + sh.nb, 4, hipMemcpyDeviceToHost, st));
-  ZG_HIP(ctx, hipMemcpyAsync((char*)pinned + PINNED_POINTS, wsum, (nsets + sh.G) * sizeof(XYZZ<F>),
+  k_export<F><<<1, 256, 0, st>>>(wsum, nsets + sh.G, wstd);
+  ZG_HIP(ctx, hipGetLastError());
+  ZG_HIP(ctx, hipMemcpyAsync((char*)pinned + PINNED_POINTS, wstd, (nsets + sh.G) * sizeof(XYZZ<F>),
                              hipMemcpyDeviceToHost, st));
   pend->nsets = nsets;
   pend->acc_kernel = is_g2 ? K_MSM_ACC0_G2 : K_MSM_ACC0_G1;

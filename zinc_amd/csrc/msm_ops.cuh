@@ -1,0 +1,102 @@
+// Point arithmetic as the multiexp kernels see it: one traits class per curve hides which field
+// representation the accumulators use and how a point is laid out in memory.
+//
+//   Pt      an accumulator as one lane holds it in registers
+//   PtMem   the same in device memory (bucket sums, partial sums); all-zero bytes = identity
+//   Aff     an affine base as one lane holds it
+//   LP      lanes that cooperate on one point (kernels index logical threads as lane / LP)
+//
+// Bases are read from the "internal packed" form the key tables are stored in (to_internal).
+#pragma once
+#include "curve29.cuh"
+
+namespace zg {
+
+template <class F>
+struct MsmOps;
+
+// G1: 29-bit-limb field (fp29.cuh), one lane per point.  Packed bases are in radix-2^261
+// Montgomery form, i.e. the ABI's radix-2^256 value times 32.
+template <>
+struct MsmOps<Fq> {
+  using Pt = G1XYZZ29;
+  using PtMem = G1XYZZ29;
+  using Aff = G1Affine29;
+  static constexpr int LP = 1;
+  static constexpr int MIN_WAVES = 4;
+
+  ZG_D static Pt inf() { return Pt::inf(); }
+  ZG_D static bool is_inf(const Pt& p) { return p.is_inf(); }
+  // false when the stored base is the point at infinity
+  ZG_D static bool load_base(const Affine<Fq>* src, bool negate, Aff* out) {
+    const Affine<Fq> a = *src;
+    if (a.is_inf()) return false;
+    out->x = unpack29<Fq29Params>(a.x);
+    const Fq29 y = unpack29<Fq29Params>(a.y);
+    Fq29 ny;
+#pragma unroll
+    for (int i = 0; i < 9; i++) ny.v[i] = negate ? Fq29Params::K3[i] - y.v[i] : y.v[i];
+    out->y = norm(ny);  // y or 3p - y
+    return true;
+  }
+  ZG_D static void madd(Pt& acc, const Aff& b) { add_mixed29(acc, b); }
+  ZG_D static void add(Pt& acc, const Pt& o) { add_full29(acc, o); }
+  ZG_D static Pt dbl(const Pt& p) { return dbl29(p); }
+  ZG_D static Pt load(const PtMem* p) { return *p; }
+  ZG_D static void store(PtMem* p, const Pt& v) { *p = v; }
+  ZG_D static Pt shfl_down(const Pt& p, int d) {
+    Pt o;
+    const uint32_t* src = (const uint32_t*)&p;
+    uint32_t* dst = (uint32_t*)&o;
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(Pt) / 4); i++) dst[i] = __shfl_down(src[i], d);
+    return o;
+  }
+  // the library-wide XYZZ form (radix-2^256 Montgomery, canonical) for the host
+  ZG_D static void store_std(XYZZ<Fq>* dst, const Pt& p) { *dst = export_xyzz<Fq29Params, FqParams>(p); }
+  // ABI form -> internal packed form
+  ZG_HD static Affine<Fq> to_internal(Affine<Fq> a) {
+    for (int k = 0; k < 5; k++) {
+      a.x = zg::dbl(a.x);
+      a.y = zg::dbl(a.y);
+    }
+    return a;
+  }
+};
+
+// G2: saturated 32-bit limbs over Fq2 (curve.cuh), one lane per point, bases in the ABI form.
+template <>
+struct MsmOps<Fq2> {
+  using Pt = XYZZ<Fq2>;
+  using PtMem = XYZZ<Fq2>;
+  using Aff = Affine<Fq2>;
+  static constexpr int LP = 1;
+  static constexpr int MIN_WAVES = 1;
+
+  ZG_D static Pt inf() { return Pt::inf(); }
+  ZG_D static bool is_inf(const Pt& p) { return p.is_inf(); }
+  ZG_D static bool load_base(const Affine<Fq2>* src, bool negate, Aff* out) {
+    Aff a = *src;
+    if (a.is_inf()) return false;
+    if (negate) a.y = neg(a.y);
+    *out = a;
+    return true;
+  }
+  ZG_D static void madd(Pt& acc, const Aff& b) { add_mixed(acc, b); }
+  ZG_D static void add(Pt& acc, const Pt& o) { add_full(acc, o); }
+  ZG_D static Pt dbl(const Pt& p) { return zg::dbl(p); }
+  ZG_D static Pt load(const PtMem* p) { return *p; }
+  ZG_D static void store(PtMem* p, const Pt& v) { *p = v; }
+  ZG_D static Pt shfl_down(const Pt& p, int d) {
+    Pt o;
+    const uint32_t* src = (const uint32_t*)&p;
+    uint32_t* dst = (uint32_t*)&o;
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(Pt) / 4); i++) dst[i] = __shfl_down(src[i], d);
+    return o;
+  }
+  ZG_D static void store_std(XYZZ<Fq2>* dst, const Pt& p) { *dst = p; }
+  ZG_HD static Affine<Fq2> to_internal(const Affine<Fq2>& a) { return a; }
+};
+
+}  // namespace zg
