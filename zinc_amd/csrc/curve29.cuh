@@ -123,6 +123,116 @@ ZG_D void add_full29(XYZZ29<P>& acc, const XYZZ29<P>& p) {
   acc.zzz = mul(mul(acc.zzz, p.zzz), ppp);
 }
 
+// ---- G2 over a lane pair -----------------------------------------------------------------------
+// The same formulas over Fq2 with every value split across lanes 2k (real) and 2k+1 (imaginary), see
+// mul_pair.  XYZZ29 / Affine29 then hold ONE lane's components.  Bounds in units of p, per component:
+//   stored points:  X < 6,  Y < 4,  ZZ, ZZZ < 2;   affine bases canonical (< 1)
+// The comment after a product is (bound of a) * (bound of b + multiple used for -b) <= 169.
+template <class P>
+ZG_D bool pair_is_inf(const XYZZ29<P>& p) {
+  return pair_both(p.zz.is_zero_limbs());
+}
+template <class P>
+ZG_D Fp29<P> pair_one() {
+  return (threadIdx.x & 1) ? Fp29<P>::zero() : Fp29<P>::one();
+}
+
+template <class P>
+ZG_D XYZZ29<P> dbl_affine_pair(const Affine29<P>& p) {
+  using F = Fp29<P>;
+  const F u = mul_small_k(p.y, 2);                          // <2
+  const F v = mul_pair(u, u, P::KS3);                       // 2*5
+  const F w = mul_pair(u, v, P::KS2);                       // 2*4
+  const F s = mul_pair(p.x, v, P::KS2);                     // 1*4
+  const F m = mul_small_k(mul_pair(p.x, p.x, P::KS2), 3);   // 1*3 -> <1.1, times 3: <3.3
+  const F x3 = sub2_k(mul_pair(m, m, P::KS4), F::zero(), s, P::K4);  // 3.3*7.3 -> <1.2 ; < 5.2
+  const F t = sub_k(s, x3, P::K6);                          // <7.1
+  const F y3 = sub_k(mul_pair(t, m, P::KS4), mul_pair(p.y, w, P::KS2), P::K2);  // 7.1*7.3 ; <3.4
+  return {x3, y3, v, w};
+}
+
+template <class P>
+ZG_D XYZZ29<P> dbl_pair(const XYZZ29<P>& p) {
+  using F = Fp29<P>;
+  if (pair_is_inf(p)) return p;
+  const F u = mul_small_k(p.y, 2);                          // <8
+  const F v = mul_pair(u, u, P::KS8);                       // 8*16 = 128 -> <1.76
+  const F w = mul_pair(u, v, P::KS2);                       // 8*3.76
+  const F s = mul_pair(p.x, v, P::KS2);                     // 6*3.76
+  const F m = mul_small_k(mul_pair(p.x, p.x, P::KS6), 3);   // 6*12 = 72 -> <1.43, times 3: <4.3
+  const F x3 = sub2_k(mul_pair(m, m, P::KS6), F::zero(), s, P::K4);  // 4.3*10.3 -> <1.27 ; 2s < 2.3 ; <5.3
+  const F t = sub_k(s, x3, P::K6);                          // <7.2
+  const F y3 = sub_k(mul_pair(t, m, P::KS6), mul_pair(p.y, w, P::KS2), P::K2);  // 7.2*10.3 = 74 ; 4*3.2 ; <3.5
+  return {x3, y3, mul_pair(p.zz, v, P::KS2), mul_pair(p.zzz, w, P::KS2)};
+}
+
+// acc += p (affine, not the identity)
+template <class P>
+ZG_D void add_mixed_pair(XYZZ29<P>& acc, const Affine29<P>& p) {
+  using F = Fp29<P>;
+  if (pair_is_inf(acc)) {
+    acc = {p.x, p.y, pair_one<P>(), pair_one<P>()};
+    return;
+  }
+  const F u2 = mul_pair(acc.zz, p.x, P::KS2);       // 2*3
+  const F s2 = mul_pair(acc.zzz, p.y, P::KS2);
+  const F pp_ = sub_k(u2, acc.x, P::K6);            // <7.1
+  const F pp = mul_pair(pp_, pp_, P::KS8);          // 7.1*15.1 = 107 -> <1.64
+  if (pair_both(is_zero_mod_p(pp))) {               // same x: doubling or cancellation (rare)
+    const F r0 = sub_k(s2, acc.y, P::K4);
+    if (pair_both(is_zero_mod_p(mul_pair(r0, r0, P::KS6))))
+      acc = dbl_affine_pair(p);
+    else
+      acc = XYZZ29<P>::inf();
+    return;
+  }
+  const F r = sub_k(s2, acc.y, P::K4);              // <5.1
+  const F ppp = mul_pair(pp_, pp, P::KS2);          // 7.1*3.64
+  const F q = mul_pair(acc.x, pp, P::KS2);          // 6*3.64
+  const F x3 = sub2_k(mul_pair(r, r, P::KS6), ppp, q, P::K4);  // 5.1*11.1 = 57 -> <1.34 ; ppp + 2q < 3.5 ; <5.4
+  const F t = sub_k(q, x3, P::K6);                  // <7.2
+  const F y3 = sub_k(mul_pair(t, r, P::KS6), mul_pair(acc.y, ppp, P::KS2), P::K2);  // 7.2*11.1 = 80 ; <3.5
+  acc.x = x3;
+  acc.y = y3;
+  acc.zz = mul_pair(acc.zz, pp, P::KS2);
+  acc.zzz = mul_pair(acc.zzz, ppp, P::KS2);
+}
+
+// acc += p (XYZZ)
+template <class P>
+ZG_D void add_full_pair(XYZZ29<P>& acc, const XYZZ29<P>& p) {
+  using F = Fp29<P>;
+  if (pair_is_inf(p)) return;
+  if (pair_is_inf(acc)) {
+    acc = p;
+    return;
+  }
+  const F u1 = mul_pair(acc.x, p.zz, P::KS2);       // 6*4
+  const F u2 = mul_pair(p.x, acc.zz, P::KS2);
+  const F s1 = mul_pair(acc.y, p.zzz, P::KS2);
+  const F s2 = mul_pair(p.y, acc.zzz, P::KS2);
+  const F pp_ = sub_k(u2, u1, P::K2);               // <3.2
+  const F pp = mul_pair(pp_, pp_, P::KS4);          // 3.2*7.2
+  if (pair_both(is_zero_mod_p(pp))) {
+    const F r0 = sub_k(s2, s1, P::K2);
+    if (pair_both(is_zero_mod_p(mul_pair(r0, r0, P::KS4))))
+      acc = dbl_pair(acc);
+    else
+      acc = XYZZ29<P>::inf();
+    return;
+  }
+  const F r = sub_k(s2, s1, P::K2);                 // <3.2
+  const F ppp = mul_pair(pp_, pp, P::KS2);
+  const F q = mul_pair(u1, pp, P::KS2);
+  const F x3 = sub2_k(mul_pair(r, r, P::KS4), ppp, q, P::K4);  // <5.2
+  const F t = sub_k(q, x3, P::K6);                  // <7.2
+  const F y3 = sub_k(mul_pair(t, r, P::KS4), mul_pair(s1, ppp, P::KS2), P::K2);  // 7.2*7.2 ; <3.4
+  acc.x = x3;
+  acc.y = y3;
+  acc.zz = mul_pair(mul_pair(acc.zz, p.zz, P::KS2), pp, P::KS2);
+  acc.zzz = mul_pair(mul_pair(acc.zzz, p.zzz, P::KS2), ppp, P::KS2);
+}
+
 // ---- memory formats -------------------------------------------------------------------------
 // Packed affine base (x || y, 8 x 32-bit words each, canonical, radix-2^261 Montgomery form).
 template <class P, class Q>

@@ -165,6 +165,66 @@ ZG_D Fp29<P> sqr(const Fp29<P>& a) {
   return r;
 }
 
+// ---- Fq2 = Fq[u]/(u^2 + 1) spread over a lane pair ---------------------------------------------------
+// Lane 2k holds the real component of every Fq2 value, lane 2k+1 the imaginary one.  Additions
+// and subtractions are the single-lane ones; a product needs the partner's components, fetched
+// with one DPP move per limb, and then both lanes run the same code:
+//   real: a0*b0 + a1*(K - b1)      imaginary: a1*b0 + a0*b1
+// as ONE column scan over both products with one Montgomery reduction (243 multiply-adds).
+ZG_D uint32_t pair_swap(uint32_t x) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true);
+}
+template <class P>
+ZG_D Fp29<P> pair_swap(const Fp29<P>& a) {
+  Fp29<P> r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.v[i] = pair_swap(a.v[i]);
+  return r;
+}
+ZG_D bool pair_both(bool x) { return x && pair_swap((uint32_t)x) != 0; }
+
+// This lane's component of a*b.  b's components must have normalised limbs and lie below the multiple
+// KS of p (one of P::KS*) with a margin; the result is below 2p when
+// (bound of a) * (bound of b + KS / p) <= 169, and has normalised limbs.
+template <class P>
+ZG_D Fp29<P> mul_pair(const Fp29<P>& a, const Fp29<P>& b, const uint32_t (&KS)[9]) {
+  const bool im = (threadIdx.x & 1) != 0;
+  const Fp29<P> ao = pair_swap(a), bo = pair_swap(b);
+  uint32_t v[9], z[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    v[i] = im ? bo.v[i] : b.v[i];
+    z[i] = im ? b.v[i] : KS[i] - bo.v[i];
+  }
+  uint32_t m[9];
+  Fp29<P> r;
+  uint64_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < 17; k++) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      const int j = k - i;
+      if (j >= 0 && j < 9) {
+        acc = mad64(a.v[i], v[j], acc);
+        acc = mad64(ao.v[i], z[j], acc);
+      }
+    }
+    if (k < 9) {
+#pragma unroll
+      for (int i = 0; i < k; i++) acc = mad64(m[i], P::MOD[k - i], acc);
+      m[k] = ((uint32_t)acc * P::INV) & MASK29;
+      acc = mad64(m[k], P::MOD[0], acc);
+    } else {
+#pragma unroll
+      for (int i = k - 8; i < 9; i++) acc = mad64(m[i], P::MOD[k - i], acc);
+      r.v[k - 9] = (uint32_t)acc & MASK29;
+    }
+    acc >>= 29;
+  }
+  r.v[8] = (uint32_t)acc;
+  return r;
+}
+
 // Is the product-normalised value a (below 2p, limbs strictly below 2^29) zero modulo p?
 template <class P>
 ZG_D bool is_zero_mod_p(const Fp29<P>& a) {

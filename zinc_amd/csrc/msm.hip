@@ -756,10 +756,9 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
   const size_t o_zero_end = o;
   const size_t o_rec0 = o;   o += align(max_entries * sizeof(uint2));  // coarse-sorted entries
   const size_t o_rec = o;    o += align(max_entries * sizeof(uint2));  // bucket-sorted entries
-  // k_accumulate runs a fixed number of lanes: one full round of the GPU at the occupancy its
-  // registers allow (G1 four waves per SIMD, G2 one; G2 gets two rounds so that its chunks stay short).
+  // k_accumulate runs a fixed number of logical threads: one full round of the GPU at four waves per SIMD.
   constexpr bool is_g2 = sizeof(F) > sizeof(Fq);
-  const uint32_t lanes = (uint32_t)ctx->cu_count * 4 * 64 * (is_g2 ? 2 : 4);
+  const uint32_t lanes = (uint32_t)ctx->cu_count * 4 * 64 * 4 / MsmOps<F>::LP;
   const size_t o_keys1 = o;  o += align(2 * (size_t)lanes * 4);
   using PtMem = typename MsmOps<F>::PtMem;
   const size_t o_pts1 = o;   o += align(2 * (size_t)lanes * sizeof(PtMem));
@@ -768,7 +767,8 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
   const size_t o_wsum = o;   o += align((size_t)(nsets + sh.G) * sizeof(PtMem));
   const size_t o_wstd = o;   o += align((size_t)(nsets + sh.G) * sizeof(XYZZ<F>));  // the same for the host
   const uint32_t ntiles = (ncount + SCAN_TILE - 1) / SCAN_TILE;
-  const uint32_t red_blocks = (sh.B + 256 * RED_SEG - 1) / (256 * RED_SEG);
+  constexpr uint32_t LP = MsmOps<F>::LP;
+  const uint32_t red_blocks = (sh.B + (256 / LP) * RED_SEG - 1) / ((256 / LP) * RED_SEG);
   uint32_t ones_blocks = (uint32_t)((n + 256 * 16 - 1) / (256 * 16));
   if (ones_blocks > 1024) ones_blocks = 1024;
   const size_t o_tiles = o;  o += align((size_t)(ntiles + 1) * 4);
@@ -828,12 +828,12 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
   {
     // work units (additions actually performed) are added by msm_collect from the entry count
     KernelTimer kt(ctx, is_g2 ? K_MSM_ACC0_G2 : K_MSM_ACC0_G1, 0.0, st);
-    k_accumulate<F><<<lanes / 256, 256, 0, st>>>(jt, sh.nb, lanes, rec, off, keys1, pts1, bsum, err);
+    k_accumulate<F><<<lanes * LP / 256, 256, 0, st>>>(jt, sh.nb, lanes, rec, off, keys1, pts1, bsum, err);
   }
   {
     KernelTimer kt(ctx, is_g2 ? K_MSM_ACCN_G2 : K_MSM_ACCN_G1, (double)sh.nb, st);
     constexpr int L = 2;
-    k_combine<F, L><<<(unsigned)(((size_t)sh.nb * L + 255) / 256), 256, 0, st>>>(
+    k_combine<F, L><<<(unsigned)(((size_t)sh.nb * L * LP + 255) / 256), 256, 0, st>>>(
         sh.nb, lanes, off, keys1, pts1, bsum, err + 2, (uint32_t*)(base + o_heavy));
     k_heavy<F><<<256, 256, 0, st>>>(err + 2, (const uint32_t*)(base + o_heavy), off, sh.nb, lanes, keys1, pts1, bsum);
   }
@@ -846,7 +846,7 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
   if (ms.side) ZG_HIP(ctx, hipStreamWaitEvent(st, ms.ev_join, 0));
   ZG_HIP(ctx, hipMemcpyAsync(pinned, err, 4, hipMemcpyDeviceToHost, st));
   ZG_HIP(ctx, hipMemcpyAsync((char*)pinned + 4, off + sh.nb, 4, hipMemcpyDeviceToHost, st));
-  k_export<F><<<1, 256, 0, st>>>(wsum, nsets + sh.G, wstd);
+  k_export<F><<<(nsets + sh.G) * LP / 256 + 1, 256, 0, st>>>(wsum, nsets + sh.G, wstd);
   ZG_HIP(ctx, hipGetLastError());
   ZG_HIP(ctx, hipMemcpyAsync((char*)pinned + PINNED_POINTS, wstd, (nsets + sh.G) * sizeof(XYZZ<F>),
                              hipMemcpyDeviceToHost, st));

@@ -64,29 +64,37 @@ struct MsmOps<Fq> {
   }
 };
 
-// G2: saturated 32-bit limbs over Fq2 (curve.cuh), one lane per point, bases in the ABI form.
+// G2: the same 29-bit-limb field with every Fq2 value spread over a lane pair (even lane: real
+// components, odd lane: imaginary ones), so a G2 lane has the register footprint of a G1 lane.
+// Packed bases are x.c0 | x.c1 | y.c0 | y.c1 in radix-2^261 Montgomery form.
 template <>
 struct MsmOps<Fq2> {
-  using Pt = XYZZ<Fq2>;
-  using PtMem = XYZZ<Fq2>;
-  using Aff = Affine<Fq2>;
-  static constexpr int LP = 1;
-  static constexpr int MIN_WAVES = 1;
+  using Pt = G1XYZZ29;  // one lane's components
+  struct PtMem {
+    Pt half[2];
+  };
+  using Aff = G1Affine29;
+  static constexpr int LP = 2;
+  static constexpr int MIN_WAVES = 3;
 
+  ZG_D static int sub() { return threadIdx.x & 1; }
   ZG_D static Pt inf() { return Pt::inf(); }
-  ZG_D static bool is_inf(const Pt& p) { return p.is_inf(); }
+  ZG_D static bool is_inf(const Pt& p) { return pair_is_inf(p); }
   ZG_D static bool load_base(const Affine<Fq2>* src, bool negate, Aff* out) {
-    Aff a = *src;
-    if (a.is_inf()) return false;
-    if (negate) a.y = neg(a.y);
-    *out = a;
+    const Fq* c = (const Fq*)src;
+    const Fq x = c[sub()];
+    Fq y = c[2 + sub()];
+    if (pair_both(x.is_zero() && y.is_zero())) return false;
+    if (negate) y = neg(y);
+    out->x = unpack29<Fq29Params>(x);
+    out->y = unpack29<Fq29Params>(y);
     return true;
   }
-  ZG_D static void madd(Pt& acc, const Aff& b) { add_mixed(acc, b); }
-  ZG_D static void add(Pt& acc, const Pt& o) { add_full(acc, o); }
-  ZG_D static Pt dbl(const Pt& p) { return zg::dbl(p); }
-  ZG_D static Pt load(const PtMem* p) { return *p; }
-  ZG_D static void store(PtMem* p, const Pt& v) { *p = v; }
+  ZG_D static void madd(Pt& acc, const Aff& b) { add_mixed_pair(acc, b); }
+  ZG_D static void add(Pt& acc, const Pt& o) { add_full_pair(acc, o); }
+  ZG_D static Pt dbl(const Pt& p) { return dbl_pair(p); }
+  ZG_D static Pt load(const PtMem* p) { return p->half[sub()]; }
+  ZG_D static void store(PtMem* p, const Pt& v) { p->half[sub()] = v; }
   ZG_D static Pt shfl_down(const Pt& p, int d) {
     Pt o;
     const uint32_t* src = (const uint32_t*)&p;
@@ -95,8 +103,23 @@ struct MsmOps<Fq2> {
     for (int i = 0; i < (int)(sizeof(Pt) / 4); i++) dst[i] = __shfl_down(src[i], d);
     return o;
   }
-  ZG_D static void store_std(XYZZ<Fq2>* dst, const Pt& p) { *dst = p; }
-  ZG_HD static Affine<Fq2> to_internal(const Affine<Fq2>& a) { return a; }
+  ZG_D static void store_std(XYZZ<Fq2>* dst, const Pt& p) {
+    Fq* c = (Fq*)dst;
+    const bool inf = pair_is_inf(p);
+    c[0 + sub()] = inf ? Fq::zero() : to_r256<Fq29Params, FqParams>(p.x);
+    c[2 + sub()] = inf ? Fq::zero() : to_r256<Fq29Params, FqParams>(p.y);
+    c[4 + sub()] = inf ? Fq::zero() : to_r256<Fq29Params, FqParams>(p.zz);
+    c[6 + sub()] = inf ? Fq::zero() : to_r256<Fq29Params, FqParams>(p.zzz);
+  }
+  ZG_HD static Affine<Fq2> to_internal(Affine<Fq2> a) {
+    for (int k = 0; k < 5; k++) {
+      a.x.c0 = zg::dbl(a.x.c0);
+      a.x.c1 = zg::dbl(a.x.c1);
+      a.y.c0 = zg::dbl(a.y.c0);
+      a.y.c1 = zg::dbl(a.y.c1);
+    }
+    return a;
+  }
 };
 
 }  // namespace zg
