@@ -118,20 +118,20 @@ zg16_status zg16_ctx_create(int device_id, zg16_ctx** out) {
   zg16_ctx* ctx = new zg16_ctx();
   ctx->device = device_id;
   if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) != hipSuccess) {
+      hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->early_stream, hipStreamNonBlocking) != hipSuccess) {
     delete ctx;
     return ZG16_ERR_DEVICE;
   }
   ctx->stream = ctx->own_stream;
-  for (auto& ss : ctx->side_stream)
-    if (hipStreamCreateWithFlags(&ss, hipStreamNonBlocking) != hipSuccess) {
-      delete ctx;
-      return ZG16_ERR_DEVICE;
-    }
+  if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess) {
+    delete ctx;
+    return ZG16_ERR_DEVICE;
+  }
   int cus = 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0)
     ctx->cu_count = cus;
-  if (hipHostMalloc(&ctx->pinned, 2 * MSM_PINNED_BYTES, hipHostMallocDefault) != hipSuccess) {
+  if (hipHostMalloc(&ctx->pinned, 3 * MSM_PINNED_BYTES, hipHostMallocDefault) != hipSuccess) {
     delete ctx;
     return ZG16_ERR_DEVICE;
   }
@@ -155,8 +155,8 @@ void zg16_ctx_destroy(zg16_ctx* ctx) {
     if (e) (void)hipEventDestroy(e);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
-  for (auto& ss : ctx->side_stream)
-    if (ss) (void)hipStreamDestroy(ss);
+  if (ctx->early_stream) (void)hipStreamDestroy(ctx->early_stream);
+  if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   delete ctx;
 }
@@ -309,7 +309,7 @@ zg16_status zg16_prove_partial(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1cs
   zg16_timings& tm = ctx->timings;
   tm = zg16_timings();
   // Stage boundaries are events; nothing below waits on the host until every kernel is enqueued.
-  enum { E_BEGIN, E_Z, E_SPMV, E_NTT, E_G1, E_G2_BEGIN, E_G2_END, E_END };
+  enum { E_BEGIN, E_Z, E_SPMV, E_NTT, E_G1, E_G2_BEGIN, E_G2_END, E_END, E_Z_END = 14 };
   hipEvent_t* ev = ctx->ev;
   hipStream_t st = ctx->stream, aux = ctx->aux_stream;
   const size_t m = (size_t)1 << r->log_m;
@@ -326,16 +326,36 @@ zg16_status zg16_prove_partial(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1cs
     for (Fr* p : {a, b, c}) ZG_HIP(ctx, hipMemsetAsync(p + r->n_rows, 0, (m - r->n_rows) * sizeof(Fr), st));
   ZG_HIP(ctx, hipEventRecord(ev[E_Z], st));
 
-  // The G2 multiexp needs only the witness: it runs on the second stream beside the row
-  // evaluation, the transforms and the G1 multiexps.
-  MsmPending pend_g2, pend_g1;
+  // Three multiexp pipelines.  The G2 multiexp and the G1 queries over the witness (l, a, b_g1) need
+  // only z: they start now on their own streams and run beside the row evaluation and the transforms.
+  // The h query needs the H coefficients and follows the transforms on the main stream; the
+  // latency-bound ends of the early pipelines then hide under its accumulation.
+  MsmPending pend_g2, pend_z, pend_h;
+  char* pinned = (char*)ctx->pinned;
+  const bool tables = tc != 0;
+  // h covers coefficients 0..m-2; this shard owns [lo_h, hi_h) clipped to that range
+  const size_t hi_h = pk->hi_h < m - 1 ? pk->hi_h : m - 1;
+  const size_t lo_h = pk->lo_h < hi_h ? pk->lo_h : hi_h;
+  // the h table is laid out for the whole shard; skip the points below lo_h when the range was clipped
+  const MsmJob<Fq> job_h = {pk->h + (lo_h - pk->lo_h), a + lo_h, nullptr, hi_h - lo_h, stride(pk->lo_h, pk->hi_h), tc, 0};
+  const MsmJob<Fq> jobs_z[3] = {
+      {pk->l, z + r->n_in + pk->lo_l, nullptr, pk->hi_l - pk->lo_l, stride(pk->lo_l, pk->hi_l), tc, 0},
+      {pk->a, z, r->a_map + pk->lo_a, pk->hi_a - pk->lo_a, stride(pk->lo_a, pk->hi_a), tc, 1},
+      {pk->b1, z, r->b_map + pk->lo_b, pk->hi_b - pk->lo_b, stride(pk->lo_b, pk->hi_b), tc, 2}};
   {
     ZG_HIP(ctx, hipStreamWaitEvent(aux, ev[E_Z], 0));
     ZG_HIP(ctx, hipEventRecord(ev[E_G2_BEGIN], aux));
     MsmJob<Fq2> jb = {pk->b2, z, r->b_map + pk->lo_b, pk->hi_b - pk->lo_b, stride(pk->lo_b, pk->hi_b), tc, 0};
-    const MsmStreams ms = {aux, ctx->side_stream[1], ev[10], ev[11]};
-    ZG_TRY(msm_launch<Fq2>(ctx, ms, 2, (char*)ctx->pinned + MSM_PINNED_BYTES, &jb, 1, 1, &pend_g2));
+    const MsmStreams ms = {aux, nullptr, nullptr, nullptr};
+    ZG_TRY(msm_launch<Fq2>(ctx, ms, 2, pinned + MSM_PINNED_BYTES, &jb, 1, 1, &pend_g2));
     ZG_HIP(ctx, hipEventRecord(ev[E_G2_END], aux));
+  }
+  if (tables) {
+    hipStream_t early = ctx->early_stream;
+    ZG_HIP(ctx, hipStreamWaitEvent(early, ev[E_Z], 0));
+    const MsmStreams ms = {early, nullptr, nullptr, nullptr};
+    ZG_TRY(msm_launch<Fq>(ctx, ms, 6, pinned + 2 * MSM_PINNED_BYTES, jobs_z, 3, 3, &pend_z));
+    ZG_HIP(ctx, hipEventRecord(ev[E_Z_END], early));
   }
 
   ZG_TRY(spmv_device(ctx, r, z, a, b, c));
@@ -343,36 +363,28 @@ zg16_status zg16_prove_partial(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1cs
   ZG_TRY(h_pipeline_device(ctx, a, b, c, r->log_m));
   ZG_HIP(ctx, hipEventRecord(ev[E_NTT], st));
 
-  // One G1 launch, three results: h + l (both only enter C), the a query, the b_g1 query.
   G1XYZZ g1[3];
-  {
-    // h covers coefficients 0..m-2; this shard owns [lo_h, hi_h) clipped to that range
-    const size_t hi_h = pk->hi_h < m - 1 ? pk->hi_h : m - 1;
-    const size_t lo_h = pk->lo_h < hi_h ? pk->lo_h : hi_h;
-    // the h table is laid out for the whole shard; skip the points below lo_h when the range was clipped
-    MsmJob<Fq> jobs[4] = {
-        {pk->h + (lo_h - pk->lo_h), a + lo_h, nullptr, hi_h - lo_h, stride(pk->lo_h, pk->hi_h), tc, 0},
-        {pk->l, z + r->n_in + pk->lo_l, nullptr, pk->hi_l - pk->lo_l, stride(pk->lo_l, pk->hi_l), tc, 0},
-        {pk->a, z, r->a_map + pk->lo_a, pk->hi_a - pk->lo_a, stride(pk->lo_a, pk->hi_a), tc, 1},
-        {pk->b1, z, r->b_map + pk->lo_b, pk->hi_b - pk->lo_b, stride(pk->lo_b, pk->hi_b), tc, 2}};
-    if (tc) {
-      const MsmStreams ms = {st, ctx->side_stream[0], ev[8], ev[9]};
-      ZG_TRY(msm_launch<Fq>(ctx, ms, 1, ctx->pinned, jobs, 4, 3, &pend_g1));
-      ZG_HIP(ctx, hipEventRecord(ev[E_G1], st));
-      ZG_HIP(ctx, hipStreamWaitEvent(st, ev[E_G2_END], 0));
-      ZG_HIP(ctx, hipEventRecord(ev[E_END], st));
-      ZG_HIP(ctx, hipEventSynchronize(ev[E_END]));
-      ZG_TRY(msm_collect<Fq>(ctx, &pend_g1, g1));
-    } else {
-      // without window tables every result needs its own bucket sets: three launches in turn
-      ZG_TRY(msm_g1_device(ctx, jobs, 2, &g1[0]));
-      ZG_TRY(msm_g1_device(ctx, jobs + 2, 1, &g1[1]));
-      ZG_TRY(msm_g1_device(ctx, jobs + 3, 1, &g1[2]));
-      ZG_HIP(ctx, hipEventRecord(ev[E_G1], st));
-      ZG_HIP(ctx, hipStreamWaitEvent(st, ev[E_G2_END], 0));
-      ZG_HIP(ctx, hipEventRecord(ev[E_END], st));
-      ZG_HIP(ctx, hipEventSynchronize(ev[E_END]));
-    }
+  if (tables) {
+    const MsmStreams ms = {st, ctx->side_stream, ev[8], ev[9]};
+    ZG_TRY(msm_launch<Fq>(ctx, ms, 1, pinned, &job_h, 1, 1, &pend_h));
+    ZG_HIP(ctx, hipEventRecord(ev[E_G1], st));
+    ZG_HIP(ctx, hipStreamWaitEvent(st, ev[E_Z_END], 0));
+  } else {
+    // without window tables every result needs its own bucket sets: one blocking launch each
+    G1XYZZ h_sum;
+    ZG_TRY(msm_g1_device(ctx, &job_h, 1, &h_sum));
+    for (int k = 0; k < 3; k++) ZG_TRY(msm_g1_device(ctx, &jobs_z[k], 1, &g1[k]));
+    add_full(g1[0], h_sum);
+    ZG_HIP(ctx, hipEventRecord(ev[E_G1], st));
+  }
+  ZG_HIP(ctx, hipStreamWaitEvent(st, ev[E_G2_END], 0));
+  ZG_HIP(ctx, hipEventRecord(ev[E_END], st));
+  ZG_HIP(ctx, hipEventSynchronize(ev[E_END]));
+  if (tables) {
+    G1XYZZ h_sum;
+    ZG_TRY(msm_collect<Fq>(ctx, &pend_z, g1));
+    ZG_TRY(msm_collect<Fq>(ctx, &pend_h, &h_sum));
+    add_full(g1[0], h_sum);  // h and l both only enter C
   }
   G2XYZZ qb2;
   ZG_TRY(msm_collect<Fq2>(ctx, &pend_g2, &qb2));

@@ -43,10 +43,11 @@ struct zg16_ctx {
   hipStream_t stream = nullptr;      // stream all kernels are issued on
   hipStream_t own_stream = nullptr;  // created by the context
   hipStream_t aux_stream = nullptr;  // second stream: the G2 multiexp runs beside everything else
-  hipStream_t side_stream[2] = {};   // short side branches of the two multiexp pipelines
+  hipStream_t early_stream = nullptr;  // third stream: the G1 queries that need only the witness
+  hipStream_t side_stream = nullptr;   // side branch of the h multiexp (its unit-scalar sums)
   int cu_count = 256;
   void* pinned = nullptr;            // page-locked host memory for asynchronous result read-backs
-  hipEvent_t ev[12] = {};
+  hipEvent_t ev[16] = {};
   std::string last_error = "";
   std::map<unsigned, zg::NttDomain*> domains;  // per log2 size
   // grow-only device scratch arenas, one per independent consumer
