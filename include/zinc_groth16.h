@@ -180,8 +180,10 @@ zg16_status zg16_last_timings(const zg16_ctx* ctx, zg16_timings* out);
  * Element-wise evaluation of the device field / group primitives so tests can pin them against
  * golden vectors (pairing_ce / ff_ce semantics; those crates are not part of the reference tree).
  * field: 0 Fr, 1 Fq, 2 Fq2.  op: 0 add, 1 sub, 2 mul, 3 square, 4 negate, 5 inverse (0 -> 0).
- * group: 1 G1, 2 G2.  op: 0 double p, 1 p + q (mixed), 2 p + q (projective), 3 k * p with k a
- * Montgomery Fr.  Inputs and outputs are affine points / Montgomery limbs in host memory. */
+ * group: 1 G1, 2 G2 (saturated 32-bit-limb code: key tables, host assembly); 3 G1, 4 G2 through the
+ * arithmetic of the multiexp kernels (29-bit-limb field; G2 values spread over lane pairs).
+ * op: 0 double p, 1 p + q (mixed), 2 p + q (projective), 3 k * p with k a Montgomery Fr.
+ * Inputs and outputs are affine points / Montgomery limbs in host memory. */
 zg16_status zg16_selftest_field(zg16_ctx* ctx, int field, int op, const uint64_t* a, const uint64_t* b,
                                 size_t n, uint64_t* out);
 zg16_status zg16_selftest_group(zg16_ctx* ctx, int group, int op, const uint64_t* p, const uint64_t* q,

@@ -55,10 +55,12 @@ def test_fq2_ops_golden(gpu_ctx):
     assert list(zip(got[0::2], got[1::2])) == [tuple(int(v, 16) for v in c["mul_nonresidue"]) for c in fx["cases"]]
 
 
-@pytest.mark.parametrize("name,group", [("g1_ops", 1), ("g2_ops", 2)])
+# groups 1, 2: the saturated-limb code (key tables, assembly); 3, 4: the multiexp kernels' arithmetic
+# (29-bit limbs, G2 on lane pairs) -- both pinned by the same vectors, exceptional cases included
+@pytest.mark.parametrize("name,group", [("g1_ops", 1), ("g2_ops", 2), ("g1_ops", 3), ("g2_ops", 4)])
 def test_group_ops_golden(gpu_ctx, name, group):
     fx = golden(name + ".json")
-    to_m, from_m, w = (g1_to_mont, mont_to_g1, 8) if group == 1 else (g2_to_mont, mont_to_g2, 16)
+    to_m, from_m, w = (g1_to_mont, mont_to_g1, 8) if group in (1, 3) else (g2_to_mont, mont_to_g2, 16)
 
     def run(op, p, q):
         p = np.ascontiguousarray(p, dtype=np.uint64)
@@ -71,7 +73,7 @@ def test_group_ops_golden(gpu_ctx, name, group):
 
     P = [unhex(c["p"]) for c in fx["cases"]]
     Q = [unhex(c["q"]) for c in fx["cases"]]
-    neg = lambda p: (p[0], (-p[1]) % Q_MOD) if group == 1 else (p[0], ((-p[1][0]) % Q_MOD, (-p[1][1]) % Q_MOD))
+    neg = lambda p: (p[0], (-p[1]) % Q_MOD) if group in (1, 3) else (p[0], ((-p[1][0]) % Q_MOD, (-p[1][1]) % Q_MOD))
     assert run(0, to_m(P), to_m(P)) == [unhex(c["dbl"]) for c in fx["cases"]]
     for op in (1, 2):  # mixed and projective addition, including every exceptional case
         assert run(op, to_m(P), to_m(Q)) == [unhex(c["add"]) for c in fx["cases"]]

@@ -144,3 +144,39 @@ def test_two_rank_gloo_gather_and_finish():
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert "PROOF_MATCH" in outs[0], outs[0]
+
+
+def test_fp29_bounds_hold():
+    """The lazy 29-bit-limb arithmetic of the multiexp kernels never overflows a column sum, never
+    borrows in a limb-wise subtraction and keeps every product below 2p (worst-case propagation)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "check_fp29_bounds.py")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all bounds hold" in out.stdout
+
+
+def test_fp29_constants_in_sync(tmp_path):
+    """fp29_consts.inc is what tools/gen_fp29_consts.py generates, and the constants are what they claim."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fresh = tmp_path / "consts.inc"
+    subprocess.run([sys.executable, os.path.join(root, "tools", "gen_fp29_consts.py"), str(fresh)], check=True)
+    committed = open(os.path.join(root, "zinc_amd", "csrc", "fp29_consts.inc")).read()
+    assert fresh.read_text() == committed
+    import re
+    q = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+    block = committed.split("struct Fr29Params")[0]
+    arrays = {m.group(1): [int(x.rstrip("u"), 16) for x in m.group(2).split(",")]
+              for m in re.finditer(r"uint32_t (\w+)\[9\] = \{([^}]*)\}", block)}
+    val = lambda l: sum(v << (29 * i) for i, v in enumerate(l))
+    assert val(arrays["MOD"]) == q
+    assert val(arrays["ONE"]) == (1 << 261) % q
+    for name, l in arrays.items():
+        if name.startswith("K"):
+            k = int(name.lstrip("KS"))
+            assert val(l) == k * q, name
+            lend = 30 if name.startswith("KS") else 31
+            assert all(v >= (1 << lend) - (1 << (lend - 29)) for v in l[:8]) and all(0 <= v < 1 << 32 for v in l)

@@ -4,6 +4,7 @@
 
 #define ZG_OUTLINE_FIELD_MUL 1
 #include "common.cuh"
+#include "msm_ops.cuh"
 
 namespace zg {
 
@@ -45,6 +46,68 @@ __global__ void k_group_op(int op, const Affine<F>* p, const void* q, Affine<F>*
     acc = scalar_mul(acc, k.v);
   }
   out[i] = to_affine(acc);
+}
+
+// The same group operations through the arithmetic the multiexp kernels use (MsmOps: 29-bit-limb
+// field, G2 spread over lane pairs).  p and q arrive in the kernels' packed base form; the result is
+// written as an XYZZ point in the library-wide form.
+template <class F>
+__global__ __launch_bounds__(64) void k_group_op_msm(int op, const Affine<F>* p, const void* q, XYZZ<F>* out, uint32_t n) {
+  using O = MsmOps<F>;
+  const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) / O::LP;
+  if (i >= n) return;
+  typename O::Pt acc = O::inf();
+  typename O::Aff a;
+  if (O::load_base(p + i, false, &a)) O::madd(acc, a);
+  if (op == 0) {
+    acc = O::dbl(acc);
+  } else if (op == 1) {
+    if (O::load_base((const Affine<F>*)q + i, false, &a)) O::madd(acc, a);
+  } else if (op == 2) {
+    // route the second operand through a non-trivial XYZZ representation (2q - q)
+    typename O::Pt t = O::inf();
+    if (O::load_base((const Affine<F>*)q + i, false, &a)) {
+      O::madd(t, a);
+      t = O::dbl(t);
+      O::load_base((const Affine<F>*)q + i, true, &a);
+      O::madd(t, a);
+    }
+    O::add(acc, t);
+  } else {
+    const Fr k = from_mont(((const Fr*)q)[i]);
+    typename O::Pt r = O::inf();
+    for (int w = 7; w >= 0; w--)
+      for (int b = 31; b >= 0; b--) {
+        r = O::dbl(r);
+        if ((k.v[w] >> b) & 1) O::add(r, acc);
+      }
+    acc = r;
+  }
+  O::store_std(out + i, acc);
+}
+
+template <class F>
+static zg16_status run_group_msm(zg16_ctx* ctx, int op, const uint64_t* p, const uint64_t* q, size_t n, uint64_t* out) {
+  char* buf;
+  const size_t pb = n * sizeof(Affine<F>), qb = op == 3 ? n * sizeof(Fr) : pb, ob = n * sizeof(XYZZ<F>);
+  const size_t pa = (pb + 255) & ~(size_t)255, qa = (qb + 255) & ~(size_t)255;
+  ZG_TRY(scratch_get(ctx, 5, pa + qa + ob + 256, (void**)&buf));
+  ZG_HIP(ctx, hipMemcpyAsync(buf, p, pb, hipMemcpyHostToDevice, ctx->stream));
+  if (op != 0) ZG_HIP(ctx, hipMemcpyAsync(buf + pa, q, qb, hipMemcpyHostToDevice, ctx->stream));
+  ZG_TRY(msm_build_table<F>(ctx, (Affine<F>*)buf, n, 0));
+  if (op == 1 || op == 2) ZG_TRY(msm_build_table<F>(ctx, (Affine<F>*)(buf + pa), n, 0));
+  const unsigned lanes = (unsigned)n * MsmOps<F>::LP;
+  k_group_op_msm<F><<<(lanes + 63) / 64, 64, 0, ctx->stream>>>(op, (const Affine<F>*)buf, buf + pa,
+                                                             (XYZZ<F>*)(buf + pa + qa), (uint32_t)n);
+  ZG_HIP(ctx, hipGetLastError());
+  std::vector<XYZZ<F>> host(n);
+  ZG_HIP(ctx, hipMemcpyAsync(host.data(), buf + pa + qa, ob, hipMemcpyDeviceToHost, ctx->stream));
+  ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (size_t i = 0; i < n; i++) {
+    const Affine<F> r = to_affine(host[i]);
+    memcpy((char*)out + i * sizeof r, &r, sizeof r);
+  }
+  return ZG16_OK;
 }
 
 template <class T>
@@ -98,6 +161,8 @@ zg16_status zg16_selftest_group(zg16_ctx* ctx, int group, int op, const uint64_t
   ZG_HIP(ctx, hipSetDevice(ctx->device));
   if (group == 1) return zg::run_group<zg::Fq>(ctx, op, p, q, n, out);
   if (group == 2) return zg::run_group<zg::Fq2>(ctx, op, p, q, n, out);
+  if (group == 3) return zg::run_group_msm<zg::Fq>(ctx, op, p, q, n, out);
+  if (group == 4) return zg::run_group_msm<zg::Fq2>(ctx, op, p, q, n, out);
   return zg::fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "unknown group %d", group);
 }
 }
