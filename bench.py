@@ -29,6 +29,7 @@ MAD_PER_FQ_MUL = 136               # 8x8 + 8x8 + 8 32-bit multiply-adds in one C
 FQ_MUL_PER_G1_MADD = 10            # XYZZ mixed addition: 8M + 2S
 FQ_MUL_PER_G2_MADD = 8 * 3 + 2 * 2  # Fq2 mul = 3 Fq mul (Karatsuba), Fq2 sqr = 2
 VALU_MAD_PEAK = 256 * 4 * 16 * 2.4e9  # v_mad_u64_u32: 16 lanes/clk/SIMD x 1024 SIMDs x 2.4 GHz
+VALU_MAD_MEASURED = 26.0e12         # sustained v_mad_u64_u32 rate of tools/microbench.hip on MI355X
 HBM_PEAK = 8.0e12
 
 TOXIC = dict(k1=0x1234567, k2=0x7654321, alpha=0xA11CE5, beta=0xBEEF77, gamma=0x6A33A, delta=0xDE17A, tau=0x7A0F00D)
@@ -43,6 +44,8 @@ def parse():
     ap.add_argument("--dense", action="store_true", help="all aux values uniform (multiexp worst case)")
     ap.add_argument("--cpu-log-rows", type=int, default=16, help="circuit size of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--split-transforms", choices=("auto", "on", "off"), default="auto",
+                    help="run the A/B/C transform chains on different ranks (auto: 3+ ranks and 2^22+ rows)")
     return ap.parse_args()
 
 
@@ -112,9 +115,12 @@ def main():
     from zinc_amd.distributed import prove_sharded
     dev = torch.device("cuda", local_rank) if world > 1 else None
 
+    split = args.split_transforms == "on" or (args.split_transforms == "auto" and world >= 3 and args.log_rows >= 22)
+    split = split and world > 1
+
     def step():
         return prove_sharded(ctx, key, mat, z_in_dev.data_ptr(), z_aux_dev.data_ptr(), 1, pk_view, rs[0], rs[1],
-                             rank, world, dev)
+                             rank, world, dev, split_transforms=split)
 
     def fence():
         if world > 1:
@@ -145,31 +151,52 @@ def main():
         per_kernel = {k: {"ms_per_step": v[0] / args.steps, "launches_per_step": v[1] / args.steps}
                       for k, v in stats.items() if v[1]}
 
-        def valu_roofline(name, fq_mul_per_add):
+        pmc = {}
+        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_2p%d.json" % args.log_rows)
+        if os.path.exists(pmc_path):
+            pmc = json.load(open(pmc_path))["kernels"]
+
+        def traffic(pmc_name, streaming):
+            """HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
+            (FETCH_SIZE doubled for streaming reads as gfx950 needs; raw for gathers), or None."""
+            k = pmc.get(pmc_name)
+            if not k:
+                return None
+            return (k["fetch_bytes_per_launch"] if streaming else k["fetch_bytes_per_launch_raw"]) + k["write_bytes_per_launch"]
+
+        def valu_roofline(name, fq_mul_per_add, pmc_name):
             ms, launches, adds = stats[name]
             if not launches:
                 return None
             ach = adds * fq_mul_per_add * MAD_PER_FQ_MUL / (ms * 1e-3)
             return {"kernel": name, "bound": "valu", "achieved": ach / 1e12, "peak": VALU_MAD_PEAK / 1e12,
-                    "unit": "Tmad/s", "frac": ach / VALU_MAD_PEAK, "traffic": None,
-                    "avg_launch_ms": ms / launches, "adds_per_launch": adds / launches}
+                    "unit": "Tmad/s", "frac": ach / VALU_MAD_PEAK, "traffic": traffic(pmc_name, False),
+                    "avg_launch_ms": ms / launches, "adds_per_launch": adds / launches,
+                    "frac_of_measured_mad_rate": ach / VALU_MAD_MEASURED}
 
-        def hbm_roofline(name):
+        def hbm_roofline(name, pmc_name, fr_mul_per_byte=None):
             ms, launches, nbytes = stats[name]
             if not launches:
                 return None
             ach = nbytes / (ms * 1e-3)
-            return {"kernel": name, "bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK, "traffic": None, "avg_launch_ms": ms / launches,
-                    "bytes_per_launch": nbytes / launches}
+            r = {"kernel": name, "bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                 "frac": ach / HBM_PEAK, "traffic": traffic(pmc_name, True), "avg_launch_ms": ms / launches,
+                 "bytes_per_launch": nbytes / launches}
+            if fr_mul_per_byte:
+                # the transform is bounded by field products, not bytes: the same launches against the VALU peak
+                mads = nbytes * fr_mul_per_byte * MAD_PER_FQ_MUL / (ms * 1e-3)
+                r["valu_achieved_Tmad_s"] = mads / 1e12
+                r["valu_frac"] = mads / VALU_MAD_PEAK
+            return r
 
+        # k_ntt_pass: a radix-2^10 pass spends 5 butterfly products + 1 twiddle product per element = 6 per 64 bytes
         rooflines = {
-            "k_accumulate<G1,level0>": valu_roofline("k_accumulate<G1,level0>", FQ_MUL_PER_G1_MADD),
-            "k_accumulate<G2,level0>": valu_roofline("k_accumulate<G2,level0>", FQ_MUL_PER_G2_MADD),
-            "k_ntt_pass": hbm_roofline("k_ntt_pass"),
-            "k_spmv_short+long": hbm_roofline("k_spmv_short+long"),
+            "k_accumulate<G1>": valu_roofline("k_accumulate<G1>", FQ_MUL_PER_G1_MADD, "k_accumulate<Fq >"),
+            "k_accumulate<G2>": valu_roofline("k_accumulate<G2>", FQ_MUL_PER_G2_MADD, "k_accumulate<Fq2>"),
+            "k_ntt_pass": hbm_roofline("k_ntt_pass", "k_ntt_pass", 6.0 / 64.0),
+            "k_spmv_short+long": hbm_roofline("k_spmv_short+long", "k_spmv_short"),
         }
-        roofline = rooflines.get(dom[0]) or rooflines["k_accumulate<G1,level0>"]
+        roofline = rooflines.get(dom[0]) or rooflines["k_accumulate<G1>"]
         out = {
             "metric": "groth16_prove_latency_2^%d_constraints" % args.log_rows,
             "value": ms_per_step / 1e3,
@@ -186,7 +213,7 @@ def main():
             "config": {"workload": "synthetic zinc-shaped R1CS, 2^%d rows (%s witness), full Groth16 prove incl. G2 multiexp"
                                    % (args.log_rows, "dense" if args.dense else "80% bit"),
                        "n_inputs": circ.n_inputs, "n_aux": circ.n_aux, "nnz": [int(m[1].shape[0]) for m in r1cs.mats],
-                       "a_aux_density": dens[0], "b_aux_density": dens[2], "parallelism": "msm-point-range x%d" % world},
+                       "a_aux_density": dens[0], "b_aux_density": dens[2], "parallelism": "msm-point-range x%d%s" % (world, ", A/B/C transform chains on 3 ranks" if split else "")},
             "constraints_per_s": n_rows / (ms_per_step / 1e3),
             "stage_ms_last_step": stage,
             "kernels": per_kernel,
@@ -194,7 +221,7 @@ def main():
             "roofline_other": {k: v for k, v in rooflines.items() if v and v is not roofline},
             "setup_s_untimed": setup_s,
         }
-        g1 = stats["k_accumulate<G1,level0>"]
+        g1 = stats["k_accumulate<G1>"]
         if g1[0]:
             out["msm_g1_accumulate_points_per_s"] = g1[2] / (g1[0] * 1e-3)
         if world == 1 and not args.no_cpu_baseline:

@@ -138,6 +138,25 @@ zg16_status zg16_prove_finish(const zg16_pk_view* vk_points, const zg16_partial*
                               size_t n_partials, const uint64_t r[4], const uint64_t s[4],
                               zg16_proof* out);
 
+/* Transform split for three or more GPUs.  bellman runs three independent chains before it can form H
+ * (row evaluation of A, B or C, then `ifft`, then `coset_fft`); each chain can run on its own GPU:
+ *   zg16_eval_chain      rows of matrix `which` (0 = A, 1 = B, 2 = C) times z, ifft, coset_fft -> out_dev,
+ *                        2^log_m Fr of DEVICE memory owned by the caller
+ *   (the caller moves the B and C vectors to the GPU that holds A: two point-to-point copies)
+ *   zg16_h_from_cosets   a <- icoset_fft((a*b - c) / Z): the H coefficients, device memory, in place
+ *   (the caller broadcasts H)
+ *   zg16_prove_partial_h zg16_prove_partial with the H coefficients supplied (device memory, 2^log_m Fr)
+ * zg16_r1cs_log_domain returns log_m.  No counterpart call exists upstream: bellman_ce does all of it inside
+ * `create_proof` on one host (zinc-vm/src/core/circuit/facade.rs:153). */
+zg16_status zg16_eval_chain(zg16_ctx* ctx, const zg16_r1cs* r1cs, const uint64_t* z_in,
+                            const uint64_t* z_aux, int witness_on_device, int which, uint64_t* out_dev);
+zg16_status zg16_h_from_cosets(zg16_ctx* ctx, uint64_t* a_dev, const uint64_t* b_dev,
+                               const uint64_t* c_dev, unsigned log_m);
+zg16_status zg16_prove_partial_h(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1cs* r1cs,
+                                 const uint64_t* z_in, const uint64_t* z_aux, int witness_on_device,
+                                 const uint64_t* h_dev, zg16_partial* out);
+unsigned    zg16_r1cs_log_domain(const zg16_r1cs* r1cs);
+
 /* ---- stand-alone stages (each is one stage of bellman's prover) ------------------------------
  * data: 2^log_n Montgomery Fr, natural order in and out, transformed in place.
  * inverse = 0: `EvaluationDomain::fft`; inverse = 1: `ifft` (includes the 1/m factor);

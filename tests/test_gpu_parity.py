@@ -2,6 +2,7 @@
 seeded inputs, and size-independent properties at the benchmark's full sizes.  Bar: bit-exact
 (all arithmetic is integer / modular; there is no floating point on this path)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -393,3 +394,29 @@ def test_cpp_host_mirror_driver(gpu_ctx, tmp_path):
     path.write_bytes(blob)
     res = subprocess.run([exe, str(path)], capture_output=True, text=True, timeout=120)
     assert res.returncode == 0, res.stdout + res.stderr
+
+
+# ------------------------------------------------------------------------------ multi-process
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_prove_with_split_transforms(world):
+    """`world` processes on one GPU (gloo stands in for RCCL): key sharded by point range, the A/B/C
+    transform chains on different ranks, H broadcast, partials gathered -- bit-identical to zg16_prove."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "tests", "gpu_split_worker.py")
+    env = dict(os.environ, PYTHONPATH=root)
+    port = 29540 + world
+    procs = [subprocess.Popen([sys.executable, script, str(r), str(world), str(port), "12"], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=100)[0].decode())
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "bit-identical" in outs[0], outs[0]

@@ -300,8 +300,12 @@ zg16_status zg16_r1cs_density(const zg16_r1cs* r, size_t* a_aux, size_t* b_input
 }
 
 // ---------------------------------------------------------------------------------------- prove
-zg16_status zg16_prove_partial(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1cs* r, const uint64_t* z_in,
-                               const uint64_t* z_aux, int on_device, zg16_partial* out) {
+}  // extern "C"
+
+// One GPU's share of a proof.  h_external: device array of the H coefficients (2^log_m entries) computed
+// elsewhere, or null to evaluate the rows and run the transforms here.
+static zg16_status prove_partial_impl(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1cs* r, const uint64_t* z_in,
+                                      const uint64_t* z_aux, int on_device, const Fr* h_external, zg16_partial* out) {
   if (!ctx || !pk || !r || !out) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "bad arguments to zg16_prove_partial");
   if (pk->ctx != ctx || r->ctx != ctx) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "handles belong to another context");
   ZG_TRY(check_key_fits(ctx, pk, r));
@@ -319,11 +323,15 @@ zg16_status zg16_prove_partial(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1cs
   ZG_HIP(ctx, hipEventRecord(ev[E_BEGIN], st));
   Fr* z;
   ZG_TRY(stage_witness(ctx, r, z_in, z_aux, on_device, &z));
-  Fr* abc;
-  ZG_TRY(scratch_get(ctx, 4, 3 * m * sizeof(Fr), (void**)&abc));
-  Fr *a = abc, *b = abc + m, *c = abc + 2 * m;
-  if (m > r->n_rows)
-    for (Fr* p : {a, b, c}) ZG_HIP(ctx, hipMemsetAsync(p + r->n_rows, 0, (m - r->n_rows) * sizeof(Fr), st));
+  Fr *a = nullptr, *b = nullptr, *c = nullptr;
+  if (!h_external) {
+    Fr* abc;
+    ZG_TRY(scratch_get(ctx, 4, 3 * m * sizeof(Fr), (void**)&abc));
+    a = abc; b = abc + m; c = abc + 2 * m;
+    if (m > r->n_rows)
+      for (Fr* p : {a, b, c}) ZG_HIP(ctx, hipMemsetAsync(p + r->n_rows, 0, (m - r->n_rows) * sizeof(Fr), st));
+  }
+  const Fr* h_coeffs = h_external ? h_external : a;
   ZG_HIP(ctx, hipEventRecord(ev[E_Z], st));
 
   // Three multiexp pipelines.  The G2 multiexp and the G1 queries over the witness (l, a, b_g1) need
@@ -337,7 +345,7 @@ zg16_status zg16_prove_partial(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1cs
   const size_t hi_h = pk->hi_h < m - 1 ? pk->hi_h : m - 1;
   const size_t lo_h = pk->lo_h < hi_h ? pk->lo_h : hi_h;
   // the h table is laid out for the whole shard; skip the points below lo_h when the range was clipped
-  const MsmJob<Fq> job_h = {pk->h + (lo_h - pk->lo_h), a + lo_h, nullptr, hi_h - lo_h, stride(pk->lo_h, pk->hi_h), tc, 0};
+  const MsmJob<Fq> job_h = {pk->h + (lo_h - pk->lo_h), h_coeffs + lo_h, nullptr, hi_h - lo_h, stride(pk->lo_h, pk->hi_h), tc, 0};
   const MsmJob<Fq> jobs_z[3] = {
       {pk->l, z + r->n_in + pk->lo_l, nullptr, pk->hi_l - pk->lo_l, stride(pk->lo_l, pk->hi_l), tc, 0},
       {pk->a, z, r->a_map + pk->lo_a, pk->hi_a - pk->lo_a, stride(pk->lo_a, pk->hi_a), tc, 1},
@@ -358,9 +366,9 @@ zg16_status zg16_prove_partial(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1cs
     ZG_HIP(ctx, hipEventRecord(ev[E_Z_END], early));
   }
 
-  ZG_TRY(spmv_device(ctx, r, z, a, b, c));
+  if (!h_external) ZG_TRY(spmv_device(ctx, r, z, a, b, c));
   ZG_HIP(ctx, hipEventRecord(ev[E_SPMV], st));
-  ZG_TRY(h_pipeline_device(ctx, a, b, c, r->log_m));
+  if (!h_external) ZG_TRY(h_pipeline_device(ctx, a, b, c, r->log_m));
   ZG_HIP(ctx, hipEventRecord(ev[E_NTT], st));
 
   G1XYZZ g1[3];
@@ -401,6 +409,50 @@ zg16_status zg16_prove_partial(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1cs
   profile_collect(ctx);
   return ZG16_OK;
 }
+
+extern "C" {
+
+zg16_status zg16_prove_partial(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1cs* r, const uint64_t* z_in,
+                               const uint64_t* z_aux, int on_device, zg16_partial* out) {
+  return prove_partial_impl(ctx, pk, r, z_in, z_aux, on_device, nullptr, out);
+}
+
+zg16_status zg16_prove_partial_h(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1cs* r, const uint64_t* z_in,
+                                 const uint64_t* z_aux, int on_device, const uint64_t* h_dev, zg16_partial* out) {
+  if (!h_dev) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "zg16_prove_partial_h needs the H coefficients");
+  return prove_partial_impl(ctx, pk, r, z_in, z_aux, on_device, (const Fr*)h_dev, out);
+}
+
+// Coset evaluations of one of the three row-evaluation polynomials: rows of matrix `which` times z,
+// ifft, coset_fft.  out_dev: 2^log_m elements of device memory.
+zg16_status zg16_eval_chain(zg16_ctx* ctx, const zg16_r1cs* r, const uint64_t* z_in, const uint64_t* z_aux, int on_device,
+                            int which, uint64_t* out_dev) {
+  if (!ctx || !r || !out_dev || which < 0 || which > 2) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "bad arguments to zg16_eval_chain");
+  if (r->ctx != ctx) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "handle belongs to another context");
+  ZG_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t m = (size_t)1 << r->log_m;
+  Fr* z;
+  ZG_TRY(stage_witness(ctx, r, z_in, z_aux, on_device, &z));
+  Fr* out = (Fr*)out_dev;
+  if (m > r->n_rows) ZG_HIP(ctx, hipMemsetAsync(out + r->n_rows, 0, (m - r->n_rows) * sizeof(Fr), ctx->stream));
+  ZG_TRY(spmv_one_device(ctx, r, which, z, out));
+  ZG_TRY(coset_evals_device(ctx, out, r->log_m));
+  ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ZG16_OK;
+}
+
+// a_dev <- H coefficients from the three coset evaluation vectors (device memory, 2^log_m each):
+// a*b - c, divide by Z on the coset, icoset_fft.  The first 2^log_m - 1 entries are the h-query scalars.
+zg16_status zg16_h_from_cosets(zg16_ctx* ctx, uint64_t* a_dev, const uint64_t* b_dev, const uint64_t* c_dev, unsigned log_m) {
+  if (!ctx || !a_dev || !b_dev || !c_dev) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "bad arguments to zg16_h_from_cosets");
+  if (log_m >= 28) return fail(ctx, ZG16_ERR_POLYNOMIAL_DEGREE_TOO_LARGE, "domain 2^%u exceeds 2^27", log_m);
+  ZG_HIP(ctx, hipSetDevice(ctx->device));
+  ZG_TRY(h_finish_device(ctx, (Fr*)a_dev, (const Fr*)b_dev, (const Fr*)c_dev, log_m));
+  ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ZG16_OK;
+}
+
+unsigned zg16_r1cs_log_domain(const zg16_r1cs* r) { return r ? r->log_m : 0; }
 
 zg16_status zg16_prove_finish(const zg16_pk_view* v, const zg16_partial* parts, size_t n_parts, const uint64_t r_[4],
                               const uint64_t s_[4], zg16_proof* out) {
@@ -476,7 +528,7 @@ zg16_status zg16_prove(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1cs* r, con
 
 static const char* const kKernelNames[K_COUNT] = {
     "k_spmv_short+long", "k_ntt_pass", "k_scale_powers", "k_mul_sub_scale", "k_sort_*+k_fine_*+k_scan_*", "k_scan",
-    "k_accumulate<G1,level0>", "k_accumulate<G2,level0>", "k_accumulate<G1,level>=1>", "k_accumulate<G2,level>=1>",
+    "k_accumulate<G1>", "k_accumulate<G2>", "k_combine+k_heavy<G1>", "k_combine+k_heavy<G2>",
     "k_bucket_reduce<G1>", "k_bucket_reduce<G2>", "k_sum_range<G1>", "k_sum_range<G2>"};
 
 zg16_status zg16_profile_enable(zg16_ctx* ctx, int on) {

@@ -162,6 +162,9 @@ zg16_status ntt_device(zg16_ctx* ctx, Fr* data, unsigned log_n, bool inverse, bo
 // a, b, c: device arrays of 2^log_m elements (zero-padded row evaluations); on return `a` holds
 // the icoset_fft output whose first m-1 entries are the H coefficients.  b, c are clobbered.
 zg16_status h_pipeline_device(zg16_ctx* ctx, Fr* a, Fr* b, Fr* c, unsigned log_m);
+// The two halves of it: ifft + coset_fft of one vector in place; a <- icoset_fft((a*b - c) / Z).
+zg16_status coset_evals_device(zg16_ctx* ctx, Fr* p, unsigned log_m);
+zg16_status h_finish_device(zg16_ctx* ctx, Fr* a, const Fr* b, const Fr* c, unsigned log_m);
 
 // One multiexp term list: result[group] += sum_k scalar(k) * bases[k], k < n, where
 // scalar(k) = scalars[index ? index[k] : k] (Montgomery Fr, device memory).

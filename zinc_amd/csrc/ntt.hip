@@ -15,20 +15,17 @@
 
 namespace zg {
 
-static constexpr unsigned LO_BITS = 12;
-static constexpr unsigned LO_SIZE = 1u << LO_BITS;
 static constexpr unsigned MAX_RADIX_BITS = 10;
 static constexpr unsigned TILE_ELEMS = 1024;
 
+// Every table is a full one (N entries): with 288 GB of HBM a few multiples of the domain size cost
+// nothing, and a twiddle or a coset factor is then one 32-byte load instead of a field product.
 struct NttDomain {
   unsigned log_n = 0;
-  Fr* w_lo[2] = {};   // [dir][4096]   w^e           (dir 1 = inverse root)
-  Fr* w_hi[2] = {};   // [dir][N>>12]  w^(4096 e)
-  Fr* g_lo = nullptr;      // g^i
-  Fr* gm_lo = nullptr;     // g^i / m
-  Fr* ginvm_lo = nullptr;  // g^-i / m
-  Fr* g_hi = nullptr;      // g^(4096 i)
-  Fr* ginv_hi = nullptr;   // g^-(4096 i)
+  Fr* w[2] = {};           // [dir][N]  w^e  (dir 1 = inverse root)
+  Fr* g = nullptr;         // g^i
+  Fr* gm = nullptr;        // g^i / m
+  Fr* ginvm = nullptr;     // g^-i / m
   Fr* w_small[2] = {};     // [dir][512]  w_1024^e
   Fr minv, zinv;           // 1/m, 1/(g^m - 1)
   Fr* block = nullptr;     // one allocation behind all of the above
@@ -41,18 +38,24 @@ struct PassParams {
   uint32_t in_hi, in_lo, out_hi, out_lo, tw_lo_mul;
   uint32_t tw_scale;  // 0: no inter-pass twiddle
   uint32_t load_j_fast;
+  uint32_t post_scale;  // multiply output element i by scale[i] (last pass only)
 };
 
-__global__ void k_pow_table(Fr* out, uint32_t count, Fr base, Fr c) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= count) return;
-  out[i] = mul(c, pow_u64(base, i));
+// out[i] = c * base^i.  A workgroup raises base to its first index once and then each lane walks
+// 16 consecutive powers, so the table costs ~1 product per entry.
+__global__ __launch_bounds__(256) void k_pow_table(Fr* out, uint32_t count, Fr base, Fr c) {
+  const uint32_t first = (blockIdx.x * blockDim.x + threadIdx.x) * 16;
+  if (first >= count) return;
+  Fr v = mul(c, pow_u64(base, first));
+  for (uint32_t k = 0; k < 16 && first + k < count; k++) {
+    out[first + k] = v;
+    v = mul(v, base);
+  }
 }
 
 __global__ __launch_bounds__(256) void k_ntt_pass(const Fr* __restrict__ in, Fr* __restrict__ out,
                                                   PassParams p, const Fr* __restrict__ w_small,
-                                                  const Fr* __restrict__ tw_lo,
-                                                  const Fr* __restrict__ tw_hi) {
+                                                  const Fr* __restrict__ tw, const Fr* __restrict__ scale) {
   __shared__ Fr s[TILE_ELEMS];
   const uint32_t tid = threadIdx.x;
   const uint32_t logR = p.logR, logT = p.logT;
@@ -96,24 +99,18 @@ __global__ __launch_bounds__(256) void k_ntt_pass(const Fr* __restrict__ in, Fr*
     Fr v = s[(t << logR) + (__brev(kk) >> (32 - logR))];
     if (p.tw_scale) {
       const uint32_t e = (m0 + t) * kk * p.tw_scale;
-      if (e) {
-        Fr tw = tw_lo[e & (LO_SIZE - 1)];
-        if (e >> LO_BITS) tw = mul(tw, tw_hi[e >> LO_BITS]);
-        v = mul(v, tw);
-      }
+      if (e) v = mul(v, tw[e]);
     }
-    out[out_base + kk * p.out_jstride + t * p.out_tstride] = v;
+    const uint32_t o = out_base + kk * p.out_jstride + t * p.out_tstride;
+    if (p.post_scale) v = mul(v, scale[o]);
+    out[o] = v;
   }
 }
 
-// x[i] *= lo[i mod 4096] * hi[i / 4096]
-__global__ __launch_bounds__(256) void k_scale_powers(Fr* x, uint32_t n, const Fr* __restrict__ lo,
-                                                      const Fr* __restrict__ hi) {
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    Fr t = lo[i & (LO_SIZE - 1)];
-    if (i >> LO_BITS) t = mul(t, hi[i >> LO_BITS]);
-    x[i] = mul(x[i], t);
-  }
+// x[i] *= table[i]
+__global__ __launch_bounds__(256) void k_scale_powers(Fr* x, uint32_t n, const Fr* __restrict__ table) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    x[i] = mul(x[i], table[i]);
 }
 
 __global__ __launch_bounds__(256) void k_scale_const(Fr* x, uint32_t n, Fr c) {
@@ -151,23 +148,19 @@ static zg16_status get_domain(zg16_ctx* ctx, unsigned log_n, NttDomain** out) {
   if (log_n >= 28) return fail(ctx, ZG16_ERR_POLYNOMIAL_DEGREE_TOO_LARGE, "domain 2^%u exceeds 2^27", log_n);
   NttDomain* d = new NttDomain();
   d->log_n = log_n;
-  const size_t n_hi = log_n > LO_BITS ? ((size_t)1 << (log_n - LO_BITS)) : 1;
-  const size_t total = 5 * (size_t)LO_SIZE + 4 * n_hi + 2 * 512;
+  const size_t N = (size_t)1 << log_n;
+  const size_t total = 5 * N + 2 * 512;
   hipError_t e = hipMalloc(&d->block, total * sizeof(Fr));
   if (e != hipSuccess) {
     delete d;
     return fail(ctx, ZG16_ERR_OUT_OF_MEMORY, "hipMalloc of NTT tables failed: %s", hipGetErrorString(e));
   }
   Fr* p = d->block;
-  d->w_lo[0] = p; p += LO_SIZE;
-  d->w_lo[1] = p; p += LO_SIZE;
-  d->g_lo = p; p += LO_SIZE;
-  d->gm_lo = p; p += LO_SIZE;
-  d->ginvm_lo = p; p += LO_SIZE;
-  d->w_hi[0] = p; p += n_hi;
-  d->w_hi[1] = p; p += n_hi;
-  d->g_hi = p; p += n_hi;
-  d->ginv_hi = p; p += n_hi;
+  d->w[0] = p; p += N;
+  d->w[1] = p; p += N;
+  d->g = p; p += N;
+  d->gm = p; p += N;
+  d->ginvm = p; p += N;
   d->w_small[0] = p; p += 512;
   d->w_small[1] = p; p += 512;
 
@@ -183,17 +176,13 @@ static zg16_status get_domain(zg16_ctx* ctx, unsigned log_n, NttDomain** out) {
   d->zinv = inv(sub(pow_u64(g, (uint64_t)1 << log_n), one));
   hipStream_t st = ctx->stream;
   auto launch = [&](Fr* dst, size_t count, const Fr& base, const Fr& c) {
-    k_pow_table<<<(unsigned)((count + 255) / 256), 256, 0, st>>>(dst, (uint32_t)count, base, c);
+    k_pow_table<<<(unsigned)((count + 4095) / 4096), 256, 0, st>>>(dst, (uint32_t)count, base, c);
   };
-  launch(d->w_lo[0], LO_SIZE, omega, one);
-  launch(d->w_lo[1], LO_SIZE, omega_inv, one);
-  launch(d->g_lo, LO_SIZE, g, one);
-  launch(d->gm_lo, LO_SIZE, g, d->minv);
-  launch(d->ginvm_lo, LO_SIZE, g_inv, d->minv);
-  launch(d->w_hi[0], n_hi, pow_u64(omega, LO_SIZE), one);
-  launch(d->w_hi[1], n_hi, pow_u64(omega_inv, LO_SIZE), one);
-  launch(d->g_hi, n_hi, pow_u64(g, LO_SIZE), one);
-  launch(d->ginv_hi, n_hi, pow_u64(g_inv, LO_SIZE), one);
+  launch(d->w[0], N, omega, one);
+  launch(d->w[1], N, omega_inv, one);
+  launch(d->g, N, g, one);
+  launch(d->gm, N, g, d->minv);
+  launch(d->ginvm, N, g_inv, d->minv);
   launch(d->w_small[0], 512, w1024, one);
   launch(d->w_small[1], 512, w1024_inv, one);
   ZG_HIP(ctx, hipGetLastError());
@@ -221,11 +210,15 @@ static unsigned max_radix_bits() {
   return v;
 }
 
-// Unnormalised transform: dst = DFT_{w^+-1}(src).  dst may alias src.
-static zg16_status ntt_raw(zg16_ctx* ctx, NttDomain* d, const Fr* src, Fr* dst, bool inverse) {
+// Unnormalised transform: dst[i] = DFT_{w^+-1}(src)[i] * (post_scale ? post_scale[i] : 1).  dst may
+// alias src.  The factor rides on the last pass's store, so `ifft` followed by a coset scaling (or
+// `icoset_fft`'s trailing g^-i / m) costs one extra product per element and no extra pass.
+static zg16_status ntt_raw(zg16_ctx* ctx, NttDomain* d, const Fr* src, Fr* dst, bool inverse,
+                           const Fr* post_scale = nullptr) {
   const unsigned n = d->log_n;
   if (n == 0) {
     if (dst != src) ZG_HIP(ctx, hipMemcpyAsync(dst, src, sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
+    if (post_scale) k_scale_powers<<<1, 256, 0, ctx->stream>>>(dst, 1, post_scale);
     return ZG16_OK;
   }
   const unsigned rb = max_radix_bits();
@@ -258,7 +251,7 @@ static zg16_status ntt_raw(zg16_ctx* ctx, NttDomain* d, const Fr* src, Fr* dst, 
     p.tw_scale = 1;
     const uint32_t grid = (R2 * R3) >> p.logT;
     KernelTimer kt(ctx, K_NTT_PASS, 64.0 * (double)((size_t)1 << n));
-    k_ntt_pass<<<grid, 256, 0, st>>>(src, tmp, p, d->w_small[dir], d->w_lo[dir], d->w_hi[dir]);
+    k_ntt_pass<<<grid, 256, 0, st>>>(src, tmp, p, d->w_small[dir], d->w[dir], nullptr);
   }
   if (r2) {  // pass B: over i2, tile of adjacent i3, one k1 per block row
     PassParams p = {};
@@ -272,7 +265,7 @@ static zg16_status ntt_raw(zg16_ctx* ctx, NttDomain* d, const Fr* src, Fr* dst, 
     p.tw_scale = R1;
     const uint32_t grid = R1 * (R3 >> p.logT);
     KernelTimer kt(ctx, K_NTT_PASS, 64.0 * (double)((size_t)1 << n));
-    k_ntt_pass<<<grid, 256, 0, st>>>(tmp, tmp, p, d->w_small[dir], d->w_lo[dir], d->w_hi[dir]);
+    k_ntt_pass<<<grid, 256, 0, st>>>(tmp, tmp, p, d->w_small[dir], d->w[dir], nullptr);
   }
   {  // pass C: over i3 (contiguous), tile of adjacent k1, scatter to natural order
     PassParams p = {};
@@ -289,9 +282,10 @@ static zg16_status ntt_raw(zg16_ctx* ctx, NttDomain* d, const Fr* src, Fr* dst, 
     p.out_lo = R1;
     p.tw_scale = 0;
     p.load_j_fast = 1;
+    p.post_scale = post_scale ? 1 : 0;
     const uint32_t grid = (R1 >> p.logT) * R2;
     KernelTimer kt(ctx, K_NTT_PASS, 64.0 * (double)((size_t)1 << n));
-    k_ntt_pass<<<grid, 256, 0, st>>>(r1 ? tmp : src, dst, p, d->w_small[dir], d->w_lo[dir], d->w_hi[dir]);
+    k_ntt_pass<<<grid, 256, 0, st>>>(r1 ? tmp : src, dst, p, d->w_small[dir], d->w[dir], post_scale);
   }
   ZG_HIP(ctx, hipGetLastError());
   return ZG16_OK;
@@ -308,45 +302,46 @@ zg16_status ntt_device(zg16_ctx* ctx, Fr* data, unsigned log_n, bool inverse, bo
   const uint32_t n = 1u << log_n;
   hipStream_t st = ctx->stream;
   if (!inverse) {
-    if (coset) k_scale_powers<<<ew_grid(n), 256, 0, st>>>(data, n, d->g_lo, d->g_hi);
+    if (coset) k_scale_powers<<<ew_grid(n), 256, 0, st>>>(data, n, d->g);
     ZG_TRY(ntt_raw(ctx, d, data, data, false));
+  } else if (coset) {
+    ZG_TRY(ntt_raw(ctx, d, data, data, true, d->ginvm));
   } else {
     ZG_TRY(ntt_raw(ctx, d, data, data, true));
-    if (coset)
-      k_scale_powers<<<ew_grid(n), 256, 0, st>>>(data, n, d->ginvm_lo, d->ginv_hi);
-    else
-      k_scale_const<<<ew_grid(n), 256, 0, st>>>(data, n, d->minv);
+    k_scale_const<<<ew_grid(n), 256, 0, st>>>(data, n, d->minv);
   }
   ZG_HIP(ctx, hipGetLastError());
   return ZG16_OK;
 }
 
-zg16_status h_pipeline_device(zg16_ctx* ctx, Fr* a, Fr* b, Fr* c, unsigned log_m) {
+// ifft then coset_fft of one vector of row evaluations, in place.
+zg16_status coset_evals_device(zg16_ctx* ctx, Fr* p, unsigned log_m) {
+  NttDomain* d;
+  ZG_TRY(get_domain(ctx, log_m, &d));
+  // the 1/m of the ifft and the coset factors g^i are one table (g^i / m) applied as the inverse
+  // transform stores its result
+  ZG_TRY(ntt_raw(ctx, d, p, p, true, d->gm));
+  ZG_TRY(ntt_raw(ctx, d, p, p, false));
+  return ZG16_OK;
+}
+
+// a <- icoset_fft((a*b - c) / Z) for coset evaluation vectors a, b, c.
+zg16_status h_finish_device(zg16_ctx* ctx, Fr* a, const Fr* b, const Fr* c, unsigned log_m) {
   NttDomain* d;
   ZG_TRY(get_domain(ctx, log_m, &d));
   const uint32_t m = 1u << log_m;
-  hipStream_t st = ctx->stream;
-  Fr* polys[3] = {a, b, c};
-  for (Fr* p : polys) {
-    // ifft, then coset_fft; the 1/m of the ifft rides on the coset pre-scaling table
-    ZG_TRY(ntt_raw(ctx, d, p, p, true));
-    {
-      KernelTimer kt(ctx, K_NTT_SCALE, 64.0 * m);
-      k_scale_powers<<<ew_grid(m), 256, 0, st>>>(p, m, d->gm_lo, d->g_hi);
-    }
-    ZG_TRY(ntt_raw(ctx, d, p, p, false));
-  }
   {
     KernelTimer kt(ctx, K_NTT_POINTWISE, 128.0 * m);
-    k_mul_sub_scale<<<ew_grid(m), 256, 0, st>>>(a, b, c, m, d->zinv);
+    k_mul_sub_scale<<<ew_grid(m), 256, 0, ctx->stream>>>(a, b, c, m, d->zinv);
   }
-  ZG_TRY(ntt_raw(ctx, d, a, a, true));
-  {
-    KernelTimer kt(ctx, K_NTT_SCALE, 64.0 * m);
-    k_scale_powers<<<ew_grid(m), 256, 0, st>>>(a, m, d->ginvm_lo, d->ginv_hi);
-  }
+  ZG_TRY(ntt_raw(ctx, d, a, a, true, d->ginvm));
   ZG_HIP(ctx, hipGetLastError());
   return ZG16_OK;
+}
+
+zg16_status h_pipeline_device(zg16_ctx* ctx, Fr* a, Fr* b, Fr* c, unsigned log_m) {
+  for (Fr* p : {a, b, c}) ZG_TRY(coset_evals_device(ctx, p, log_m));
+  return h_finish_device(ctx, a, b, c, log_m);
 }
 
 }  // namespace zg

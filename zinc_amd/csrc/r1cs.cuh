@@ -17,6 +17,8 @@ struct R1csMatrix {
 };
 
 zg16_status spmv_device(zg16_ctx* ctx, const zg16_r1cs* r, const Fr* z, Fr* a, Fr* b, Fr* c);
+// rows of matrix k (0 = A, 1 = B, 2 = C) only
+zg16_status spmv_one_device(zg16_ctx* ctx, const zg16_r1cs* r, int k, const Fr* z, Fr* out);
 
 }  // namespace zg
 

@@ -55,20 +55,22 @@ __global__ __launch_bounds__(256) void k_spmv_long(const uint32_t* __restrict__ 
   if (lane == 0) out[r] = acc;
 }
 
+zg16_status spmv_one_device(zg16_ctx* ctx, const zg16_r1cs* r, int k, const Fr* z, Fr* out) {
+  hipStream_t st = ctx->stream;
+  const R1csMatrix& m = r->m[k];
+  KernelTimer kt(ctx, K_SPMV, (double)m.nnz * 36 + (double)(r->n_in + r->n_aux) * 32 + (double)r->n_rows * 36);
+  if (r->n_rows)
+    k_spmv_short<<<(unsigned)((r->n_rows + 255) / 256), 256, 0, st>>>(m.row_ptr, m.col, m.coeff, z, out,
+                                                                      (uint32_t)r->n_rows);
+  if (m.n_long)
+    k_spmv_long<<<(unsigned)((m.n_long + 3) / 4), 256, 0, st>>>(m.long_rows, m.n_long, m.row_ptr, m.col, m.coeff, z, out);
+  ZG_HIP(ctx, hipGetLastError());
+  return ZG16_OK;
+}
+
 zg16_status spmv_device(zg16_ctx* ctx, const zg16_r1cs* r, const Fr* z, Fr* a, Fr* b, Fr* c) {
   Fr* outs[3] = {a, b, c};
-  hipStream_t st = ctx->stream;
-  for (int k = 0; k < 3; k++) {
-    const R1csMatrix& m = r->m[k];
-    KernelTimer kt(ctx, K_SPMV, (double)m.nnz * 36 + (double)(r->n_in + r->n_aux) * 32 + (double)r->n_rows * 36);
-    if (r->n_rows)
-      k_spmv_short<<<(unsigned)((r->n_rows + 255) / 256), 256, 0, st>>>(m.row_ptr, m.col, m.coeff, z, outs[k],
-                                                                        (uint32_t)r->n_rows);
-    if (m.n_long)
-      k_spmv_long<<<(unsigned)((m.n_long + 3) / 4), 256, 0, st>>>(m.long_rows, m.n_long, m.row_ptr, m.col, m.coeff, z,
-                                                                  outs[k]);
-  }
-  ZG_HIP(ctx, hipGetLastError());
+  for (int k = 0; k < 3; k++) ZG_TRY(spmv_one_device(ctx, r, k, z, outs[k]));
   return ZG16_OK;
 }
 

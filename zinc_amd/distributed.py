@@ -22,7 +22,7 @@ def gather_partials(partial, world, rank, device=None):
     import torch
     import torch.distributed as dist
     mine = torch.frombuffer(bytearray(bytes(partial)), dtype=torch.uint8)
-    if device is not None:
+    if device is not None and dist.get_backend() != "gloo":
         mine = mine.to(device)
     outs = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(outs, mine)
@@ -39,11 +39,72 @@ def finish(pk_view, partials, n, r_mont, s_mont):
     return proof
 
 
-def prove_sharded(ctx, key, mat, z_in_ptr, z_aux_ptr, on_device, pk_view, r_mont, s_mont, rank, world, device=None):
-    """One proof across `world` ranks; returns the lib.Proof on rank 0 and None elsewhere."""
+def chain_owner(which, world):
+    """Rank that runs transform chain `which` (0 = A, 1 = B, 2 = C) when the chains are split."""
+    return which % world
+
+
+def h_coefficients_split(ctx, mat, z_in_ptr, z_aux_ptr, on_device, rank, world, device):
+    """The H coefficients with the three row-evaluation / ifft / coset_fft chains on different ranks.
+
+    Chain k runs on rank k % world; the B and C coset evaluations travel point to point to rank 0
+    (two different peers, so two different xGMI links when world >= 3), rank 0 forms
+    icoset_fft((a*b - c)/Z) and broadcasts it.  Returns a device tensor of 2^log_m Fr (int64 x 4)
+    on every rank.  `device` is the torch device of this rank's GPU."""
+    import torch
+    import torch.distributed as dist
+    L = ctx._lib
+    m = 1 << L.zg16_r1cs_log_domain(mat.handle)
+    staged = dist.get_backend() == "gloo"  # CPU rehearsal: gloo moves host tensors
+
+    def move(fn, t, peer):
+        if staged:
+            h = t.cpu()
+            fn(h, peer)
+            t.copy_(h)
+        else:
+            fn(t, peer)
+
+    bufs = {}
+    for which in range(3):
+        if chain_owner(which, world) == rank or rank == 0:
+            bufs[which] = torch.empty((m, 4), dtype=torch.int64, device=device)
+    for which in range(3):
+        if chain_owner(which, world) == rank:
+            _check(ctx.handle, L.zg16_eval_chain(ctx.handle, mat.handle, C.c_void_p(z_in_ptr), C.c_void_p(z_aux_ptr),
+                                                 int(on_device), which, C.c_void_p(bufs[which].data_ptr())))
+    for which in (1, 2):
+        owner = chain_owner(which, world)
+        if owner == 0:
+            continue
+        if rank == owner:
+            move(dist.send, bufs[which], 0)
+        elif rank == 0:
+            move(dist.recv, bufs[which], owner)
+    h = bufs[0] if rank == 0 else torch.empty((m, 4), dtype=torch.int64, device=device)
+    if rank == 0:
+        _check(ctx.handle, L.zg16_h_from_cosets(ctx.handle, C.c_void_p(h.data_ptr()), C.c_void_p(bufs[1].data_ptr()),
+                                                C.c_void_p(bufs[2].data_ptr()), m.bit_length() - 1))
+    move(dist.broadcast, h, 0)
+    return h
+
+
+def prove_sharded(ctx, key, mat, z_in_ptr, z_aux_ptr, on_device, pk_view, r_mont, s_mont, rank, world, device=None,
+                  split_transforms=False):
+    """One proof across `world` ranks; returns the lib.Proof on rank 0 and None elsewhere.
+
+    split_transforms: run the A, B, C transform chains on different ranks (h_coefficients_split)
+    instead of every rank repeating all of them; pays off when the domain is large (the vectors
+    moved are 32 * 2^log_m bytes each)."""
     part = _lib.Partial()
-    _check(ctx.handle, ctx._lib.zg16_prove_partial(ctx.handle, key.handle, mat.handle, C.c_void_p(z_in_ptr),
-                                                   C.c_void_p(z_aux_ptr), int(on_device), C.byref(part)))
+    if split_transforms and world > 1:
+        h = h_coefficients_split(ctx, mat, z_in_ptr, z_aux_ptr, on_device, rank, world, device)
+        _check(ctx.handle, ctx._lib.zg16_prove_partial_h(ctx.handle, key.handle, mat.handle, C.c_void_p(z_in_ptr),
+                                                         C.c_void_p(z_aux_ptr), int(on_device),
+                                                         C.c_void_p(h.data_ptr()), C.byref(part)))
+    else:
+        _check(ctx.handle, ctx._lib.zg16_prove_partial(ctx.handle, key.handle, mat.handle, C.c_void_p(z_in_ptr),
+                                                       C.c_void_p(z_aux_ptr), int(on_device), C.byref(part)))
     if world == 1:
         return finish(pk_view, C.byref(part), 1, r_mont, s_mont)
     parts = gather_partials(part, world, rank, device)

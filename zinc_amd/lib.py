@@ -74,6 +74,11 @@ SYMBOLS = [
                              u64p, u64p, C.POINTER(Proof)]),
     ("zg16_prove_partial", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                      C.POINTER(Partial)]),
+    ("zg16_eval_chain", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    ("zg16_h_from_cosets", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint]),
+    ("zg16_prove_partial_h", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                       C.c_void_p, C.POINTER(Partial)]),
+    ("zg16_r1cs_log_domain", C.c_uint, [C.c_void_p]),
     ("zg16_prove_finish", C.c_int, [C.POINTER(PkView), C.POINTER(Partial), C.c_size_t, u64p, u64p,
                                     C.POINTER(Proof)]),
     ("zg16_ntt", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint, C.c_int, C.c_int, C.c_int]),
