@@ -176,6 +176,18 @@ zg16_status zg16_msm_g1(zg16_ctx* ctx, const uint64_t* bases, size_t n_bases,
 zg16_status zg16_msm_g2(zg16_ctx* ctx, const uint64_t* bases, size_t n_bases,
                         const uint64_t* scalars, size_t n_scalars, const uint8_t* density,
                         uint64_t out[16]);
+/* The same multiexp over a base set that stays in HBM (what a proving-key query is): upload once,
+ * multiply many scalar vectors.  With `window_tables` non-zero the upload also stores 2^(c w) * P for
+ * every window w, so all windows share one bucket set (the layout zg16_prove uses); it costs W times
+ * the memory.  `group` is 1 (G1, 64-byte points) or 2 (G2, 128-byte points).
+ * zg16_msm_resident: scalars are n Montgomery Fr in host memory, or device memory when
+ * `scalars_on_device` is non-zero; out receives the affine sum (8 or 16 limbs). */
+typedef struct zg16_bases zg16_bases;
+zg16_status zg16_bases_upload(zg16_ctx* ctx, int group, const uint64_t* bases, size_t n,
+                              int window_tables, zg16_bases** out);
+void        zg16_bases_free(zg16_bases* bases);
+zg16_status zg16_msm_resident(zg16_ctx* ctx, const zg16_bases* bases, const uint64_t* scalars,
+                              int scalars_on_device, uint64_t* out);
 /* Row evaluations <A_row, z>, <B_row, z>, <C_row, z> (n_rows Montgomery Fr each, host memory). */
 zg16_status zg16_spmv(zg16_ctx* ctx, const zg16_r1cs* r1cs, const uint64_t* z_in,
                       const uint64_t* z_aux, uint64_t* a, uint64_t* b, uint64_t* c);

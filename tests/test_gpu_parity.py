@@ -212,6 +212,38 @@ def test_msm_vs_cpu_oracle(gpu_ctx, group, n):
     assert st == 0 and np.array_equal(fn(bases[dens != 0], sc, dens), want)
 
 
+@pytest.mark.parametrize("group,n,tables", [("g1", 20000, 1), ("g1", 20000, 0), ("g2", 3000, 1), ("g1", 1, 1), ("g1", 0, 1)])
+def test_msm_resident_bases(gpu_ctx, group, n, tables):
+    """zg16_bases_upload / zg16_msm_resident (window tables or not) against the CPU oracle.  Device-resident
+    scalars are exercised by tools/bench_standalone.py (torch has to own the HIP runtime before this library
+    loads, which a pytest session cannot guarantee)."""
+    from oracle import cpu_binding as cb
+    from zinc_amd import workload
+    from zinc_amd.groth16 import ResidentBases
+    rng = np.random.default_rng(7 * n + tables)
+    g1gen, g2gen = workload._generators()
+    width = 8 if group == "g1" else 16
+    if n:
+        ks = rand_fr(rng, n)
+        bases = workload.fixed_base_g1(gpu_ctx, g1gen, ks) if group == "g1" else workload.fixed_base_g2(gpu_ctx, g2gen, ks)
+    else:
+        bases = np.zeros((0, width), dtype=np.uint64)
+    sc = rand_fr(rng, n) if n else np.zeros((0, 4), dtype=np.uint64)
+    if n > 10:
+        sc[::3] = ints_to_mont([1], R_MOD)[0]
+        sc[1::7] = 0
+    res = ResidentBases(gpu_ctx, 1 if group == "g1" else 2, bases, window_tables=bool(tables))
+    if n:
+        st, want = cb.multiexp(group, bases, sc, None, threads=8)
+        assert st == 0
+    else:
+        want = np.zeros(width, dtype=np.uint64)
+    assert np.array_equal(res.msm(sc), want)
+    if n:
+        assert np.array_equal(res.msm(sc), want)  # the handle is reusable
+    res.free()
+
+
 def test_msm_full_size_linearity(gpu_ctx):
     """2^20 points: msm(s) + msm(t) == msm(s + t) and msm(k*s) == k*msm(s), via 3-term multiexps."""
     from zinc_amd import workload

@@ -615,6 +615,65 @@ zg16_status zg16_msm_g2(zg16_ctx* ctx, const uint64_t* bases, size_t n_bases, co
   return st;
 }
 
+zg16_status zg16_bases_upload(zg16_ctx* ctx, int group, const uint64_t* bases, size_t n, int window_tables,
+                              zg16_bases** out) {
+  if (!ctx || !out || (n && !bases) || (group != 1 && group != 2))
+    return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "bad arguments to zg16_bases_upload");
+  *out = nullptr;
+  ZG_HIP(ctx, hipSetDevice(ctx->device));
+  std::unique_ptr<zg16_bases, void (*)(zg16_bases*)> b(new zg16_bases(), zg16_bases_free);
+  b->ctx = ctx;
+  b->group = group;
+  b->n = n;
+  b->table_c = window_tables ? msm_table_window(n) : 0;
+  if (group == 1) {
+    Affine<Fq>* p;
+    ZG_TRY(upload_query<Fq>(ctx, &p, bases, n, b->table_c));
+    b->points = p;
+  } else {
+    Affine<Fq2>* p;
+    ZG_TRY(upload_query<Fq2>(ctx, &p, bases, n, b->table_c));
+    b->points = p;
+  }
+  *out = b.release();
+  return ZG16_OK;
+}
+
+void zg16_bases_free(zg16_bases* b) {
+  if (!b) return;
+  if (b->ctx) (void)hipSetDevice(b->ctx->device);
+  (void)hipFree(b->points);
+  delete b;
+}
+
+zg16_status zg16_msm_resident(zg16_ctx* ctx, const zg16_bases* b, const uint64_t* scalars, int on_device, uint64_t* out) {
+  if (!ctx || !b || !out || (b->n && !scalars)) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "bad arguments to zg16_msm_resident");
+  if (b->ctx != ctx) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "handle belongs to another context");
+  ZG_HIP(ctx, hipSetDevice(ctx->device));
+  const Fr* d_s = (const Fr*)scalars;
+  if (!on_device && b->n) {
+    Fr* buf;
+    ZG_TRY(scratch_get(ctx, 5, b->n * sizeof(Fr), (void**)&buf));
+    ZG_HIP(ctx, hipMemcpyAsync(buf, scalars, b->n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    d_s = buf;
+  }
+  const size_t stride = b->table_c ? b->n : 0;
+  if (b->group == 1) {
+    MsmJob<Fq> job = {(const Affine<Fq>*)b->points, d_s, nullptr, b->n, stride, b->table_c, 0};
+    G1XYZZ res;
+    ZG_TRY(msm_g1_device(ctx, &job, 1, &res));
+    const G1Affine a = to_affine(res);
+    memcpy(out, &a, sizeof a);
+  } else {
+    MsmJob<Fq2> job = {(const Affine<Fq2>*)b->points, d_s, nullptr, b->n, stride, b->table_c, 0};
+    G2XYZZ res;
+    ZG_TRY(msm_g2_device(ctx, &job, 1, &res));
+    const G2Affine a = to_affine(res);
+    memcpy(out, &a, sizeof a);
+  }
+  return ZG16_OK;
+}
+
 zg16_status zg16_spmv(zg16_ctx* ctx, const zg16_r1cs* r, const uint64_t* z_in, const uint64_t* z_aux, uint64_t* a,
                       uint64_t* b, uint64_t* c) {
   if (!ctx || !r || !a || !b || !c) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "bad arguments to zg16_spmv");

@@ -49,3 +49,12 @@ struct zg16_pk {
   zg::G1Affine alpha_g1, beta_g1, delta_g1;
   zg::G2Affine beta_g2, delta_g2;
 };
+
+// A base set resident in HBM (zg16_bases_upload): `n` points, optionally as a window table.
+struct zg16_bases {
+  zg16_ctx* ctx = nullptr;
+  int group = 1;  // 1 = G1, 2 = G2
+  size_t n = 0;
+  uint32_t table_c = 0;
+  void* points = nullptr;  // Affine<Fq> or Affine<Fq2>, in the multiexp kernels' packed form
+};

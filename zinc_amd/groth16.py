@@ -119,6 +119,41 @@ class Context:
         return self._msm(self._lib.zg16_msm_g2, 16, bases, scalars, density)
 
 
+class ResidentBases:
+    """A base set kept in HBM for repeated multiexps (zg16_bases_upload / zg16_msm_resident)."""
+
+    def __init__(self, ctx, group, bases, window_tables=True):
+        width = 8 if group == 1 else 16
+        arr = np.ascontiguousarray(bases, dtype=np.uint64).reshape(-1, width)
+        self.ctx, self.group, self.n, self.width = ctx, group, arr.shape[0], width
+        self.handle = C.c_void_p()
+        _check(ctx.handle, ctx._lib.zg16_bases_upload(ctx.handle, group, arr.ctypes.data_as(C.c_void_p), self.n,
+                                                      int(window_tables), C.byref(self.handle)))
+
+    def msm(self, scalars=None, device_ptr=None):
+        """Sum of scalars[i] * base[i]; scalars are Montgomery Fr on the host, or `device_ptr` on the GPU."""
+        out = np.zeros(self.width, dtype=np.uint64)
+        if device_ptr is not None:
+            ptr, on_dev = C.c_void_p(device_ptr), 1
+        else:
+            sc = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+            assert sc.shape[0] == self.n
+            ptr, on_dev = sc.ctypes.data_as(C.c_void_p), 0
+        _check(self.ctx.handle, self.ctx._lib.zg16_msm_resident(self.ctx.handle, self.handle, ptr, on_dev, _lib.as_u64p(out)))
+        return out
+
+    def free(self):
+        if self.handle:
+            self.ctx._lib.zg16_bases_free(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class Proof:
     """bellman `Proof<Bn256>`: three affine points, here as canonical integers."""
 
