@@ -60,7 +60,7 @@ def cpu_baseline_leg(ctx, log_rows, dense):
     params = workload.generate_parameters(ctx, circ, TOXIC)
     r1cs = circ.r1cs()
     zi, za = circ.witness()
-    rs = ints_to_mont([0x1CEB00DA, 0x5EED5EED], R_MOD)
+    rs = ints_to_mont([pow(7, 123456789, R_MOD), pow(5, 987654321, R_MOD)], R_MOD)
     threads = min(cb.hardware_threads() or 1, int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or 1 << 30)
     st, cpu_proof, tm = cb.prove(params, r1cs, zi, za, rs[0], rs[1], threads)
     assert st == 0, "CPU baseline prover failed with status %d" % st
@@ -107,7 +107,7 @@ def main():
     zi, za = circ.witness()
     z_in_dev = torch.from_numpy(zi.view(np.int64)).cuda()
     z_aux_dev = torch.from_numpy(za.view(np.int64)).cuda()
-    rs = ints_to_mont([0x1CEB00DA, 0x5EED5EED], R_MOD)
+    rs = ints_to_mont([pow(7, 123456789, R_MOD), pow(5, 987654321, R_MOD)], R_MOD)  # full-size r, s as Fr::rand gives
     setup_s = time.time() - t0
     pk_view = params.view()
     dens = mat.density()

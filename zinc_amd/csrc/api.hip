@@ -302,10 +302,47 @@ zg16_status zg16_r1cs_density(const zg16_r1cs* r, size_t* a_aux, size_t* b_input
 // ---------------------------------------------------------------------------------------- prove
 }  // extern "C"
 
+// Final assembly (bellman_ce 0.3.0 `create_proof`, after the multiexps) in two steps, so that the part
+// that needs only the witness-side sums can run on the host while the GPU still works on the h query:
+//   A = alpha + r*delta + a_query            B = beta + s*delta + b_query (G2)
+//   C = s*A + r*(beta_g1 + b_query_g1) + (h + l)
+// which equals upstream's rs*delta + s*alpha + r*beta + s*a_query + r*b_query + h + l term by term.
+struct Assembly {
+  G1Affine alpha1, beta1, delta1;
+  G2Affine beta2, delta2;
+  Fr rc, sc;  // canonical r, s
+  G1XYZZ A, c_part;
+  G2XYZZ B;
+  void early(const G1XYZZ& qa, const G1XYZZ& qb1, const G2XYZZ& qb2) {
+    A = scalar_mul_w4(G1XYZZ::from_affine(delta1), rc.v);
+    add_mixed(A, alpha1);
+    add_full(A, qa);
+    B = scalar_mul_w4(G2XYZZ::from_affine(delta2), sc.v);
+    add_mixed(B, beta2);
+    add_full(B, qb2);
+    G1XYZZ b1 = qb1;
+    add_mixed(b1, beta1);
+    c_part = scalar_mul_w4(A, sc.v);
+    add_full(c_part, scalar_mul_w4(b1, rc.v));
+  }
+  void finish(const G1XYZZ& hl, zg16_proof* out) const {
+    G1XYZZ C = c_part;
+    add_full(C, hl);
+    const G1Affine Aa = to_affine(A), Ca = to_affine(C);
+    const G2Affine Ba = to_affine(B);
+    memcpy(out->a, &Aa, 64);
+    memcpy(out->b, &Ba, 128);
+    memcpy(out->c, &Ca, 64);
+  }
+};
+
 // One GPU's share of a proof.  h_external: device array of the H coefficients (2^log_m entries) computed
 // elsewhere, or null to evaluate the rows and run the transforms here.
+// early: when given (single-GPU proof), its witness-side step runs on the host as soon as the a, b_g1
+// and b_g2 sums are back, beside the h multiexp.
 static zg16_status prove_partial_impl(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1cs* r, const uint64_t* z_in,
-                                      const uint64_t* z_aux, int on_device, const Fr* h_external, zg16_partial* out) {
+                                      const uint64_t* z_aux, int on_device, const Fr* h_external, zg16_partial* out,
+                                      Assembly* early = nullptr) {
   if (!ctx || !pk || !r || !out) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "bad arguments to zg16_prove_partial");
   if (pk->ctx != ctx || r->ctx != ctx) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "handles belong to another context");
   ZG_TRY(check_key_fits(ctx, pk, r));
@@ -387,15 +424,27 @@ static zg16_status prove_partial_impl(zg16_ctx* ctx, const zg16_pk* pk, const zg
   }
   ZG_HIP(ctx, hipStreamWaitEvent(st, ev[E_G2_END], 0));
   ZG_HIP(ctx, hipEventRecord(ev[E_END], st));
+  G2XYZZ qb2;
+  bool early_done = false;
+  if (tables && early) {
+    ZG_HIP(ctx, hipEventSynchronize(ev[E_Z_END]));
+    ZG_HIP(ctx, hipEventSynchronize(ev[E_G2_END]));
+    ZG_TRY(msm_collect<Fq>(ctx, &pend_z, g1));
+    ZG_TRY(msm_collect<Fq2>(ctx, &pend_g2, &qb2));
+    early->early(g1[1], g1[2], qb2);
+    early_done = true;
+  }
   ZG_HIP(ctx, hipEventSynchronize(ev[E_END]));
   if (tables) {
     G1XYZZ h_sum;
-    ZG_TRY(msm_collect<Fq>(ctx, &pend_z, g1));
+    if (!early_done) ZG_TRY(msm_collect<Fq>(ctx, &pend_z, g1));
     ZG_TRY(msm_collect<Fq>(ctx, &pend_h, &h_sum));
     add_full(g1[0], h_sum);  // h and l both only enter C
   }
-  G2XYZZ qb2;
-  ZG_TRY(msm_collect<Fq2>(ctx, &pend_g2, &qb2));
+  if (!early_done) {
+    ZG_TRY(msm_collect<Fq2>(ctx, &pend_g2, &qb2));
+    if (early) early->early(g1[1], g1[2], qb2);
+  }
   memcpy(out->hl, &g1[0], sizeof g1[0]);
   memcpy(out->a, &g1[1], sizeof g1[1]);
   memcpy(out->b1, &g1[2], sizeof g1[2]);
@@ -477,30 +526,12 @@ zg16_status zg16_prove_finish(const zg16_pk_view* v, const zg16_partial* parts, 
     memcpy(&p, parts[i].b1, sizeof p); add_full(qb1, p);
     memcpy(&p2, parts[i].b2, sizeof p2); add_full(qb2, p2);
   }
-  const Fr rm = load_fr(r_), sm = load_fr(s_);
-  const Fr rc = from_mont(rm), sc = from_mont(sm), rsc = from_mont(mul(rm, sm));
-  const G1XYZZ d1 = G1XYZZ::from_affine(delta1), a1 = G1XYZZ::from_affine(alpha1), b1 = G1XYZZ::from_affine(beta1);
-  const G2XYZZ d2 = G2XYZZ::from_affine(delta2);
-  // A = alpha + r*delta + a_query
-  G1XYZZ A = scalar_mul(d1, rc.v);
-  add_mixed(A, alpha1);
-  add_full(A, qa);
-  // B = beta + s*delta + b_query   (G2)
-  G2XYZZ B = scalar_mul(d2, sc.v);
-  add_mixed(B, beta2);
-  add_full(B, qb2);
-  // C = rs*delta + s*alpha + r*beta + s*a_query + r*b_query(G1) + h + l
-  G1XYZZ C = scalar_mul(d1, rsc.v);
-  add_full(C, scalar_mul(a1, sc.v));
-  add_full(C, scalar_mul(b1, rc.v));
-  add_full(C, scalar_mul(qa, sc.v));
-  add_full(C, scalar_mul(qb1, rc.v));
-  add_full(C, hl);
-  const G1Affine Aa = to_affine(A), Ca = to_affine(C);
-  const G2Affine Ba = to_affine(B);
-  memcpy(out->a, &Aa, 64);
-  memcpy(out->b, &Ba, 128);
-  memcpy(out->c, &Ca, 64);
+  Assembly as;
+  as.alpha1 = alpha1; as.beta1 = beta1; as.delta1 = delta1; as.beta2 = beta2; as.delta2 = delta2;
+  as.rc = from_mont(load_fr(r_));
+  as.sc = from_mont(load_fr(s_));
+  as.early(qa, qb1, qb2);
+  as.finish(hl, out);
   return ZG16_OK;
 }
 
@@ -510,19 +541,20 @@ zg16_status zg16_prove(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1cs* r, con
   if (pk->shard_count != 1) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "zg16_prove needs an unsharded key");
   if (pk->delta_g1.is_inf() || pk->delta_g2.is_inf())
     return fail(ctx, ZG16_ERR_UNEXPECTED_IDENTITY, "delta is the point at infinity");
+  if (!r_ || !s_ || !out) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "bad arguments to zg16_prove");
+  Assembly as;
+  as.alpha1 = pk->alpha_g1; as.beta1 = pk->beta_g1; as.delta1 = pk->delta_g1;
+  as.beta2 = pk->beta_g2; as.delta2 = pk->delta_g2;
+  as.rc = from_mont(load_fr(r_));
+  as.sc = from_mont(load_fr(s_));
   zg16_partial part;
-  ZG_TRY(zg16_prove_partial(ctx, pk, r, z_in, z_aux, on_device, &part));
-  zg16_pk_view v = {};
-  v.alpha_g1 = (const uint64_t*)&pk->alpha_g1;
-  v.beta_g1 = (const uint64_t*)&pk->beta_g1;
-  v.beta_g2 = (const uint64_t*)&pk->beta_g2;
-  v.delta_g1 = (const uint64_t*)&pk->delta_g1;
-  v.delta_g2 = (const uint64_t*)&pk->delta_g2;
+  ZG_TRY(prove_partial_impl(ctx, pk, r, z_in, z_aux, on_device, nullptr, &part, &as));
   auto t0 = std::chrono::steady_clock::now();
-  zg16_status st = zg16_prove_finish(&v, &part, 1, r_, s_, out);
+  G1XYZZ hl;
+  memcpy(&hl, part.hl, sizeof hl);
+  as.finish(hl, out);
   ctx->timings.finish_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   ctx->timings.total_ms += ctx->timings.finish_ms;
-  if (st != ZG16_OK) return fail(ctx, st, "final assembly failed");
   return ZG16_OK;
 }
 

@@ -159,6 +159,28 @@ ZG_HD XYZZ<F> scalar_mul(const XYZZ<F>& p, const uint32_t* k) {
   return acc;
 }
 
+// The same with 4-bit windows: 14 additions for the table, then 4 doublings and at most one addition per
+// nibble (about 250 doublings + 60 additions instead of 254 + 127).
+template <class F>
+ZG_HD XYZZ<F> scalar_mul_w4(const XYZZ<F>& p, const uint32_t* k) {
+  XYZZ<F> tab[16];
+  tab[0] = XYZZ<F>::inf();
+  tab[1] = p;
+  for (int i = 2; i < 16; i++) {
+    tab[i] = tab[i - 1];
+    add_full(tab[i], p);
+  }
+  XYZZ<F> acc = XYZZ<F>::inf();
+  for (int i = 7; i >= 0; i--)
+    for (int n = 7; n >= 0; n--) {
+      if (!acc.is_inf())
+        for (int d = 0; d < 4; d++) acc = dbl(acc);
+      const uint32_t digit = (k[i] >> (4 * n)) & 15;
+      if (digit) add_full(acc, tab[digit]);
+    }
+  return acc;
+}
+
 template <class F>
 ZG_HD bool on_curve(const Affine<F>& p, const F& b) {
   if (p.is_inf()) return true;

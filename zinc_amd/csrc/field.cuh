@@ -174,42 +174,51 @@ ZG_D Fp<P> mul_inline(const Fp<P>& a, const Fp<P>& b) {
   return r;
 }
 #else
-// Montgomery product a*b*R^-1 mod p, CIOS over 32-bit digits (host).  Because p < 2^254 the running
-// value stays below 2p + epsilon, so one spare limb (t[8]) is enough.
+// Montgomery product a*b*R^-1 mod p on the host: CIOS over four 64-bit digits (the same bytes as the
+// eight 32-bit limbs on a little-endian machine).  Because p < 2^254 the running value stays below
+// 2p, so one spare digit is enough.  Used by the final assembly of A, B, C and by table set-up.
 template <class P>
 inline Fp<P> mul_inline(const Fp<P>& a, const Fp<P>& b) {
-  uint32_t t[9];
-#pragma unroll
-  for (int i = 0; i < 9; i++) t[i] = 0;
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    uint64_t c = 0;
-    const uint32_t bi = b.v[i];
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      c += (uint64_t)a.v[j] * bi + t[j];
-      t[j] = (uint32_t)c;
-      c >>= 32;
-    }
-    c += t[8];
-    t[8] = (uint32_t)c;  // bits above 2^288 cannot occur
-    const uint32_t m = t[0] * P::inv;
-    c = (uint64_t)m * P::mod(0) + t[0];
-    c >>= 32;
-#pragma unroll
-    for (int j = 1; j < 8; j++) {
-      c += (uint64_t)m * P::mod(j) + t[j];
-      t[j - 1] = (uint32_t)c;
-      c >>= 32;
-    }
-    c += t[8];
-    t[7] = (uint32_t)c;
-    t[8] = (uint32_t)(c >> 32);
+  typedef unsigned __int128 u128;
+  uint64_t x[4], y[4], p[4], t[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 4; i++) {
+    x[i] = (uint64_t)a.v[2 * i] | ((uint64_t)a.v[2 * i + 1] << 32);
+    y[i] = (uint64_t)b.v[2 * i] | ((uint64_t)b.v[2 * i + 1] << 32);
+    p[i] = (uint64_t)P::mod(2 * i) | ((uint64_t)P::mod(2 * i + 1) << 32);
   }
-  reduce_once<P>(t);
+  // -p^-1 mod 2^64 from the 32-bit constant by one Newton step: inv64 = inv32 * (2 + p * inv32)
+  const uint64_t i32 = P::inv;
+  const uint64_t inv64 = i32 * (2 + p[0] * i32);
+  for (int i = 0; i < 4; i++) {
+    u128 c = 0;
+    for (int j = 0; j < 4; j++) {
+      c += (u128)x[j] * y[i] + t[j];
+      t[j] = (uint64_t)c;
+      c >>= 64;
+    }
+    c += t[4];
+    t[4] = (uint64_t)c;
+    t[5] = (uint64_t)(c >> 64);
+    const uint64_t m = t[0] * inv64;
+    c = (u128)m * p[0] + t[0];
+    c >>= 64;
+    for (int j = 1; j < 4; j++) {
+      c += (u128)m * p[j] + t[j];
+      t[j - 1] = (uint64_t)c;
+      c >>= 64;
+    }
+    c += t[4];
+    t[3] = (uint64_t)c;
+    t[4] = t[5] + (uint64_t)(c >> 64);
+  }
+  uint32_t r32[8];
+  for (int i = 0; i < 4; i++) {
+    r32[2 * i] = (uint32_t)t[i];
+    r32[2 * i + 1] = (uint32_t)(t[i] >> 32);
+  }
+  reduce_once<P>(r32);
   Fp<P> r;
-#pragma unroll
-  for (int i = 0; i < 8; i++) r.v[i] = t[i];
+  for (int i = 0; i < 8; i++) r.v[i] = r32[i];
   return r;
 }
 #endif

@@ -96,6 +96,13 @@ def prove_sharded(ctx, key, mat, z_in_ptr, z_aux_ptr, on_device, pk_view, r_mont
     split_transforms: run the A, B, C transform chains on different ranks (h_coefficients_split)
     instead of every rank repeating all of them; pays off when the domain is large (the vectors
     moved are 32 * 2^log_m bytes each)."""
+    if world == 1:
+        # one GPU: zg16_prove overlaps the host's share of the assembly with the h multiexp
+        proof = _lib.Proof()
+        _check(ctx.handle, ctx._lib.zg16_prove(ctx.handle, key.handle, mat.handle, C.c_void_p(z_in_ptr),
+                                               C.c_void_p(z_aux_ptr), int(on_device), _lib.as_u64p(r_mont),
+                                               _lib.as_u64p(s_mont), C.byref(proof)))
+        return proof
     part = _lib.Partial()
     if split_transforms and world > 1:
         h = h_coefficients_split(ctx, mat, z_in_ptr, z_aux_ptr, on_device, rank, world, device)
@@ -105,8 +112,6 @@ def prove_sharded(ctx, key, mat, z_in_ptr, z_aux_ptr, on_device, pk_view, r_mont
     else:
         _check(ctx.handle, ctx._lib.zg16_prove_partial(ctx.handle, key.handle, mat.handle, C.c_void_p(z_in_ptr),
                                                        C.c_void_p(z_aux_ptr), int(on_device), C.byref(part)))
-    if world == 1:
-        return finish(pk_view, C.byref(part), 1, r_mont, s_mont)
     parts = gather_partials(part, world, rank, device)
     if rank != 0:
         return None
