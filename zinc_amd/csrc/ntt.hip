@@ -12,6 +12,7 @@
 // Each workgroup stages a T x R tile (T*R <= 1024 elements, 32 KiB) in LDS and runs the R-point
 // transforms there, so every pass is one read and one write of the array.
 #include "common.cuh"
+#include "fp29.cuh"
 
 namespace zg {
 
@@ -20,15 +21,17 @@ static constexpr unsigned TILE_ELEMS = 1024;
 
 // Every table is a full one (N entries): with 288 GB of HBM a few multiples of the domain size cost
 // nothing, and a twiddle or a coset factor is then one 32-byte load instead of a field product.
+// Tables the transform kernel multiplies by are kept as nine 29-bit limbs in radix-2^261 Montgomery
+// form (Fr29): the data stays in the ABI's radix-2^256 form, and x_256 * w_261 * 2^-261 is again in it.
 struct NttDomain {
   unsigned log_n = 0;
-  Fr* w[2] = {};           // [dir][N]  w^e  (dir 1 = inverse root)
-  Fr* g = nullptr;         // g^i
-  Fr* gm = nullptr;        // g^i / m
-  Fr* ginvm = nullptr;     // g^-i / m
-  Fr* w_small[2] = {};     // [dir][512]  w_1024^e
+  Fr29* w[2] = {};         // [dir][N]  w^e  (dir 1 = inverse root)
+  Fr29* gm = nullptr;      // g^i / m
+  Fr29* ginvm = nullptr;   // g^-i / m
+  Fr29* w_small[2] = {};   // [dir][512]  w_1024^e
+  Fr* g = nullptr;         // g^i (ABI form, for the stand-alone coset_fft pre-scaling)
   Fr minv, zinv;           // 1/m, 1/(g^m - 1)
-  Fr* block = nullptr;     // one allocation behind all of the above
+  void* block = nullptr;   // one allocation behind all of the above
 };
 
 struct PassParams {
@@ -53,10 +56,48 @@ __global__ __launch_bounds__(256) void k_pow_table(Fr* out, uint32_t count, Fr b
   }
 }
 
-__global__ __launch_bounds__(256) void k_ntt_pass(const Fr* __restrict__ in, Fr* __restrict__ out,
-                                                  PassParams p, const Fr* __restrict__ w_small,
-                                                  const Fr* __restrict__ tw, const Fr* __restrict__ scale) {
-  __shared__ Fr s[TILE_ELEMS];
+// ABI-form table -> Fr29 table (radix change by one product)
+__global__ __launch_bounds__(256) void k_to_fr29(const Fr* __restrict__ in, Fr29* __restrict__ out, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = from_r256<Fr29Params>(in[i]);
+}
+
+ZG_D Fr29 lds_get(const uint32_t* s, uint32_t i) {
+  Fr29 r;
+#pragma unroll
+  for (int k = 0; k < 9; k++) r.v[k] = s[i * 9 + k];
+  return r;
+}
+ZG_D void lds_put(uint32_t* s, uint32_t i, const Fr29& x) {
+#pragma unroll
+  for (int k = 0; k < 9; k++) s[i * 9 + k] = x.v[k];
+}
+
+// One decimation-in-time butterfly on lazy values: (x0, x1) <- (x0 + t, x0 - t) with t = x1 * w, or
+// t = x1 when the twiddle is one (TRIVIAL).  The subtrahend is a fresh product (below 2p) or, in the
+// trivial case, a value below `KSUB` p, so the result grows by an additive constant per stage instead
+// of doubling: ten stages keep every value below 40p (products need operand bounds whose product
+// stays below 169).  NORM_ADD: normalise the sum too (it is about to be stored or multiplied).
+template <bool TRIVIAL, bool NORM_ADD>
+ZG_D void butterfly29(Fr29& x0, Fr29& x1, const Fr29& w, const uint32_t (&K)[9]) {
+  const Fr29 t = TRIVIAL ? x1 : mul(x1, w);
+  Fr29 d;
+#pragma unroll
+  for (int k = 0; k < 9; k++) d.v[k] = x0.v[k] + K[k] - t.v[k];
+  x1 = norm(d);
+  Fr29 a = add_lazy(x0, t);
+  x0 = NORM_ADD ? norm(a) : a;
+}
+
+// One pass of the transform over a T x R tile staged in LDS (see the file comment).  Elements are
+// unpacked to nine 29-bit limbs on load, go through log2(R) decimation-in-time stages two at a time
+// (a lane holds the four elements of a radix-4 unit in registers, so LDS is touched every second
+// stage), and every output takes exactly one product -- the inter-pass twiddle, the trailing scale
+// factor, or one -- which also brings it back below 2p for the canonical packed store.
+__global__ __launch_bounds__(256, 4) void k_ntt_pass(const Fr* __restrict__ in, Fr* __restrict__ out,
+                                                     PassParams p, const Fr29* __restrict__ w_small,
+                                                     const Fr29* __restrict__ tw, const Fr29* __restrict__ scale) {
+  __shared__ uint32_t s[TILE_ELEMS * 9];
   const uint32_t tid = threadIdx.x;
   const uint32_t logR = p.logR, logT = p.logT;
   const uint32_t R = 1u << logR, T = 1u << logT, E = R << logT;
@@ -64,7 +105,9 @@ __global__ __launch_bounds__(256) void k_ntt_pass(const Fr* __restrict__ in, Fr*
   const uint32_t in_base = q * p.in_hi + rem * p.in_lo;
   const uint32_t out_base = q * p.out_hi + rem * p.out_lo;
   const uint32_t m0 = rem * p.tw_lo_mul;
+  const uint32_t wshift = MAX_RADIX_BITS - logR;  // w_R^e = w_1024^(e << wshift)
 
+  // load in bit-reversed position: decimation in time then leaves natural order
   for (uint32_t idx = tid; idx < E; idx += 256) {
     uint32_t j, t;
     if (p.load_j_fast) {
@@ -74,36 +117,71 @@ __global__ __launch_bounds__(256) void k_ntt_pass(const Fr* __restrict__ in, Fr*
       t = idx & (T - 1);
       j = idx >> logT;
     }
-    s[(t << logR) + j] = in[in_base + j * p.in_jstride + t * p.in_tstride];
+    const Fr x = in[in_base + j * p.in_jstride + t * p.in_tstride];
+    lds_put(s, (t << logR) + (__brev(j) >> (32 - logR)), unpack29<Fr29Params>(x));
   }
   __syncthreads();
 
-  // decimation in frequency: natural order in, bit-reversed order out
-  for (int st = (int)logR - 1; st >= 0; --st) {
-    const uint32_t half = 1u << st;
-    for (uint32_t b = tid; b < (E >> 1); b += 256) {
-      const uint32_t t = b >> (logR - 1), jj = b & ((R >> 1) - 1);
-      const uint32_t grp = jj >> st, pos = jj & (half - 1);
-      const uint32_t i0 = (t << logR) + (grp << (st + 1)) + pos, i1 = i0 + half;
-      const Fr x = s[i0], y = s[i1];
-      s[i0] = add(x, y);
-      Fr d = sub(x, y);
-      if (pos) d = mul(d, w_small[(pos << (logR - 1 - st)) << (MAX_RADIX_BITS - logR)]);
-      s[i1] = d;
+  uint32_t st = 0;
+  for (; st + 1 < logR; st += 2) {
+    const uint32_t h = 1u << st;
+    for (uint32_t u = tid; u < (E >> 2); u += 256) {
+      const uint32_t t = u >> (logR - 2), qq = u & ((R >> 2) - 1);
+      const uint32_t grp = qq >> st, pos = qq & (h - 1);
+      const uint32_t i0 = (t << logR) + (grp << (st + 2)) + pos;
+      Fr29 a = lds_get(s, i0), b = lds_get(s, i0 + h), c = lds_get(s, i0 + 2 * h), d = lds_get(s, i0 + 3 * h);
+      // stage st: pairs (a, b) and (c, d), twiddle w_(2h)^pos; stage st+1: pairs (a, c) with w_(4h)^pos and
+      // (b, d) with w_(4h)^(pos + h)
+      if (st == 0) {
+        // w_2^0 = w_4^0 = 1: three of the four twiddles are one (inputs are canonical, below p)
+        butterfly29<true, false>(a, b, a, Fr29Params::K2);
+        butterfly29<true, false>(c, d, c, Fr29Params::K2);
+        butterfly29<true, true>(a, c, a, Fr29Params::K4);      // c < 2p + ... below 4p
+        const Fr29 w3 = w_small[(R >> 2) << wshift];
+        butterfly29<false, true>(b, d, w3, Fr29Params::K2);
+      } else {
+        const Fr29 w1 = w_small[(pos << (logR - 1 - st)) << wshift];
+        butterfly29<false, false>(a, b, w1, Fr29Params::K2);
+        butterfly29<false, false>(c, d, w1, Fr29Params::K2);
+        const Fr29 w2 = w_small[(pos << (logR - 2 - st)) << wshift];
+        butterfly29<false, true>(a, c, w2, Fr29Params::K2);
+        const Fr29 w3 = w_small[((pos + h) << (logR - 2 - st)) << wshift];
+        butterfly29<false, true>(b, d, w3, Fr29Params::K2);
+      }
+      lds_put(s, i0, a);
+      lds_put(s, i0 + h, b);
+      lds_put(s, i0 + 2 * h, c);
+      lds_put(s, i0 + 3 * h, d);
+    }
+    __syncthreads();
+  }
+  if (st < logR) {  // odd number of stages: one radix-2 round
+    const uint32_t h = 1u << st;
+    for (uint32_t u = tid; u < (E >> 1); u += 256) {
+      const uint32_t t = u >> (logR - 1), qq = u & ((R >> 1) - 1);
+      const uint32_t grp = qq >> st, pos = qq & (h - 1);
+      const uint32_t i0 = (t << logR) + (grp << (st + 1)) + pos;
+      Fr29 a = lds_get(s, i0), b = lds_get(s, i0 + h);
+      const Fr29 w1 = w_small[(pos << (logR - 1 - st)) << wshift];
+      butterfly29<false, true>(a, b, w1, Fr29Params::K2);
+      lds_put(s, i0, a);
+      lds_put(s, i0 + h, b);
     }
     __syncthreads();
   }
 
   for (uint32_t idx = tid; idx < E; idx += 256) {
     const uint32_t t = idx & (T - 1), kk = idx >> logT;
-    Fr v = s[(t << logR) + (__brev(kk) >> (32 - logR))];
-    if (p.tw_scale) {
-      const uint32_t e = (m0 + t) * kk * p.tw_scale;
-      if (e) v = mul(v, tw[e]);
-    }
+    const Fr29 v = lds_get(s, (t << logR) + kk);
     const uint32_t o = out_base + kk * p.out_jstride + t * p.out_tstride;
-    if (p.post_scale) v = mul(v, scale[o]);
-    out[o] = v;
+    Fr29 f;
+    if (p.tw_scale)
+      f = tw[(m0 + t) * kk * p.tw_scale];
+    else if (p.post_scale)
+      f = scale[o];
+    else
+      f = Fr29::one();
+    out[o] = pack29<Fr29Params, FrParams>(mul(v, f));
   }
 }
 
@@ -149,20 +227,21 @@ static zg16_status get_domain(zg16_ctx* ctx, unsigned log_n, NttDomain** out) {
   NttDomain* d = new NttDomain();
   d->log_n = log_n;
   const size_t N = (size_t)1 << log_n;
-  const size_t total = 5 * N + 2 * 512;
-  hipError_t e = hipMalloc(&d->block, total * sizeof(Fr));
+  const size_t bytes29 = (4 * N + 2 * 512) * sizeof(Fr29), bytes = bytes29 + (2 * N + 512) * sizeof(Fr);
+  hipError_t e = hipMalloc(&d->block, bytes);
   if (e != hipSuccess) {
     delete d;
     return fail(ctx, ZG16_ERR_OUT_OF_MEMORY, "hipMalloc of NTT tables failed: %s", hipGetErrorString(e));
   }
-  Fr* p = d->block;
+  Fr29* p = (Fr29*)d->block;
   d->w[0] = p; p += N;
   d->w[1] = p; p += N;
-  d->g = p; p += N;
   d->gm = p; p += N;
   d->ginvm = p; p += N;
   d->w_small[0] = p; p += 512;
   d->w_small[1] = p; p += 512;
+  d->g = (Fr*)((char*)d->block + bytes29);
+  Fr* tmp = d->g + N;  // N + 512 elements of staging, left unused afterwards
 
   Fr omega = host_root_of_unity();
   for (unsigned i = log_n; i < 28; i++) omega = sqr(omega);
@@ -178,13 +257,17 @@ static zg16_status get_domain(zg16_ctx* ctx, unsigned log_n, NttDomain** out) {
   auto launch = [&](Fr* dst, size_t count, const Fr& base, const Fr& c) {
     k_pow_table<<<(unsigned)((count + 4095) / 4096), 256, 0, st>>>(dst, (uint32_t)count, base, c);
   };
-  launch(d->w[0], N, omega, one);
-  launch(d->w[1], N, omega_inv, one);
+  auto table29 = [&](Fr29* dst, size_t count, const Fr& base, const Fr& c) {
+    launch(tmp, count, base, c);
+    k_to_fr29<<<(unsigned)((count + 255) / 256), 256, 0, st>>>(tmp, dst, (uint32_t)count);
+  };
+  table29(d->w[0], N, omega, one);
+  table29(d->w[1], N, omega_inv, one);
+  table29(d->gm, N, g, d->minv);
+  table29(d->ginvm, N, g_inv, d->minv);
+  table29(d->w_small[0], 512, w1024, one);
+  table29(d->w_small[1], 512, w1024_inv, one);
   launch(d->g, N, g, one);
-  launch(d->gm, N, g, d->minv);
-  launch(d->ginvm, N, g_inv, d->minv);
-  launch(d->w_small[0], 512, w1024, one);
-  launch(d->w_small[1], 512, w1024_inv, one);
   ZG_HIP(ctx, hipGetLastError());
   ctx->domains[log_n] = d;
   *out = d;
@@ -214,11 +297,11 @@ static unsigned max_radix_bits() {
 // alias src.  The factor rides on the last pass's store, so `ifft` followed by a coset scaling (or
 // `icoset_fft`'s trailing g^-i / m) costs one extra product per element and no extra pass.
 static zg16_status ntt_raw(zg16_ctx* ctx, NttDomain* d, const Fr* src, Fr* dst, bool inverse,
-                           const Fr* post_scale = nullptr) {
+                           const Fr29* post_scale = nullptr) {
   const unsigned n = d->log_n;
   if (n == 0) {
     if (dst != src) ZG_HIP(ctx, hipMemcpyAsync(dst, src, sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
-    if (post_scale) k_scale_powers<<<1, 256, 0, ctx->stream>>>(dst, 1, post_scale);
+    if (post_scale) k_scale_const<<<1, 256, 0, ctx->stream>>>(dst, 1, d->minv);  // g^0 / m
     return ZG16_OK;
   }
   const unsigned rb = max_radix_bits();
