@@ -19,29 +19,37 @@ namespace zg {
 static constexpr unsigned MAX_RADIX_BITS = 10;
 static constexpr unsigned TILE_ELEMS = 1024;
 
+struct PassParams {
+  uint32_t logR, logT;
+  uint32_t in_jstride, in_tstride, out_jstride, out_tstride;
+  uint32_t bdiv;
+  uint32_t in_hi, in_lo, out_hi, out_lo, tw_lo_mul;
+  uint32_t tw_scale;  // inter-pass twiddle exponent scale (k_pass_twiddles), 0: none
+  uint32_t load_j_fast;
+};
+
+// N = R1*R2*R3: the passes of one transform and their launch sizes
+struct NttPlan {
+  unsigned r1 = 0, r2 = 0, r3 = 0;
+  PassParams a = {}, b = {}, c = {};
+  uint32_t grid_a = 0, grid_b = 0, grid_c = 0;
+};
+
 // Every table is a full one (N entries): with 288 GB of HBM a few multiples of the domain size cost
-// nothing, and a twiddle or a coset factor is then one 32-byte load instead of a field product.
+// nothing, and a twiddle or a coset factor is then one streamed load instead of a field product.
 // Tables the transform kernel multiplies by are kept as nine 29-bit limbs in radix-2^261 Montgomery
 // form (Fr29): the data stays in the ABI's radix-2^256 form, and x_256 * w_261 * 2^-261 is again in it.
 struct NttDomain {
   unsigned log_n = 0;
-  Fr29* w[2] = {};         // [dir][N]  w^e  (dir 1 = inverse root)
+  NttPlan plan;
+  Fr29* tw_a[2] = {};      // [dir][N]  pass A's inter-pass twiddles in its store order (dir 1 = inverse root)
+  Fr29* tw_b[2] = {};      // [dir][N]  pass B's (three-pass transforms only)
   Fr29* gm = nullptr;      // g^i / m
   Fr29* ginvm = nullptr;   // g^-i / m
   Fr29* w_small[2] = {};   // [dir][512]  w_1024^e
   Fr* g = nullptr;         // g^i (ABI form, for the stand-alone coset_fft pre-scaling)
   Fr minv, zinv;           // 1/m, 1/(g^m - 1)
   void* block = nullptr;   // one allocation behind all of the above
-};
-
-struct PassParams {
-  uint32_t logR, logT;
-  uint32_t in_jstride, in_tstride, out_jstride, out_tstride;
-  uint32_t bdiv;
-  uint32_t in_hi, in_lo, out_hi, out_lo, tw_lo_mul;
-  uint32_t tw_scale;  // 0: no inter-pass twiddle
-  uint32_t load_j_fast;
-  uint32_t post_scale;  // multiply output element i by scale[i] (last pass only)
 };
 
 // out[i] = c * base^i.  A workgroup raises base to its first index once and then each lane walks
@@ -96,7 +104,7 @@ ZG_D void butterfly29(Fr29& x0, Fr29& x1, const Fr29& w, const uint32_t (&K)[9])
 // factor, or one -- which also brings it back below 2p for the canonical packed store.
 __global__ __launch_bounds__(256, 4) void k_ntt_pass(const Fr* __restrict__ in, Fr* __restrict__ out,
                                                      PassParams p, const Fr29* __restrict__ w_small,
-                                                     const Fr29* __restrict__ tw, const Fr29* __restrict__ scale) {
+                                                     const Fr29* __restrict__ factor) {
   __shared__ uint32_t s[TILE_ELEMS * 9];
   const uint32_t tid = threadIdx.x;
   const uint32_t logR = p.logR, logT = p.logT;
@@ -104,7 +112,6 @@ __global__ __launch_bounds__(256, 4) void k_ntt_pass(const Fr* __restrict__ in, 
   const uint32_t q = blockIdx.x / p.bdiv, rem = blockIdx.x % p.bdiv;
   const uint32_t in_base = q * p.in_hi + rem * p.in_lo;
   const uint32_t out_base = q * p.out_hi + rem * p.out_lo;
-  const uint32_t m0 = rem * p.tw_lo_mul;
   const uint32_t wshift = MAX_RADIX_BITS - logR;  // w_R^e = w_1024^(e << wshift)
 
   // load in bit-reversed position: decimation in time then leaves natural order
@@ -174,14 +181,22 @@ __global__ __launch_bounds__(256, 4) void k_ntt_pass(const Fr* __restrict__ in, 
     const uint32_t t = idx & (T - 1), kk = idx >> logT;
     const Fr29 v = lds_get(s, (t << logR) + kk);
     const uint32_t o = out_base + kk * p.out_jstride + t * p.out_tstride;
-    Fr29 f;
-    if (p.tw_scale)
-      f = tw[(m0 + t) * kk * p.tw_scale];
-    else if (p.post_scale)
-      f = scale[o];
-    else
-      f = Fr29::one();
+    // the inter-pass twiddle or the trailing scale factor, laid out in store order (a streaming read)
+    const Fr29 f = factor ? factor[o] : Fr29::one();
     out[o] = pack29<Fr29Params, FrParams>(mul(v, f));
+  }
+}
+
+// factor[o] = w^e for the inter-pass twiddle exponent e of every element a pass stores, in store order.
+__global__ __launch_bounds__(256) void k_pass_twiddles(PassParams p, const Fr29* __restrict__ w, Fr29* __restrict__ factor) {
+  const uint32_t logR = p.logR, logT = p.logT;
+  const uint32_t T = 1u << logT, E = (1u << logR) << logT;
+  const uint32_t q = blockIdx.x / p.bdiv, rem = blockIdx.x % p.bdiv;
+  const uint32_t out_base = q * p.out_hi + rem * p.out_lo;
+  const uint32_t m0 = rem * p.tw_lo_mul;
+  for (uint32_t idx = threadIdx.x; idx < E; idx += 256) {
+    const uint32_t t = idx & (T - 1), kk = idx >> logT;
+    factor[out_base + kk * p.out_jstride + t * p.out_tstride] = w[(m0 + t) * kk * p.tw_scale];
   }
 }
 
@@ -217,6 +232,77 @@ static Fr host_root_of_unity() {
   return pow_limbs(from_u64<FrParams>(7), sh, 8);
 }
 
+static unsigned max_radix_bits() {
+  static unsigned v = 0;
+  if (!v) {
+    const char* e = getenv("ZG16_NTT_RADIX_BITS");
+    v = e ? (unsigned)atoi(e) : MAX_RADIX_BITS;
+    if (v < 2) v = 2;
+    if (v > MAX_RADIX_BITS) v = MAX_RADIX_BITS;
+  }
+  return v;
+}
+
+static NttPlan make_plan(unsigned n) {
+  NttPlan pl;
+  const unsigned rb = max_radix_bits();
+  unsigned r1, r2, r3;
+  if (n <= rb) {
+    r1 = 0; r2 = 0; r3 = n;
+  } else if (n <= 2 * rb) {
+    r1 = (n + 1) / 2; r2 = 0; r3 = n - r1;
+  } else {
+    r1 = (n + 2) / 3; r2 = (n - r1 + 1) / 2; r3 = n - r1 - r2;
+  }
+  pl.r1 = r1; pl.r2 = r2; pl.r3 = r3;
+  const uint32_t R1 = 1u << r1, R2 = 1u << r2, R3 = 1u << r3;
+  auto tile_bits = [](unsigned rbits, unsigned limit_bits) {
+    unsigned t = 10 - rbits;  // TILE_ELEMS / R
+    return t < limit_bits ? t : limit_bits;
+  };
+  if (r1) {  // pass A: over i1, tile of adjacent (i2,i3)
+    PassParams& p = pl.a;
+    p.logR = r1;
+    p.logT = tile_bits(r1, r2 + r3);
+    p.in_jstride = p.out_jstride = R2 * R3;
+    p.in_tstride = p.out_tstride = 1;
+    p.bdiv = 0x80000000u;
+    p.in_lo = p.out_lo = p.tw_lo_mul = 1u << p.logT;
+    p.tw_scale = 1;
+    pl.grid_a = (R2 * R3) >> p.logT;
+  }
+  if (r2) {  // pass B: over i2, tile of adjacent i3, one k1 per block row
+    PassParams& p = pl.b;
+    p.logR = r2;
+    p.logT = tile_bits(r2, r3);
+    p.in_jstride = p.out_jstride = R3;
+    p.in_tstride = p.out_tstride = 1;
+    p.bdiv = R3 >> p.logT;
+    p.in_hi = p.out_hi = R2 * R3;
+    p.in_lo = p.out_lo = p.tw_lo_mul = 1u << p.logT;
+    p.tw_scale = R1;
+    pl.grid_b = R1 * (R3 >> p.logT);
+  }
+  {  // pass C: over i3 (contiguous), tile of adjacent k1, scatter to natural order
+    PassParams& p = pl.c;
+    p.logR = r3;
+    p.logT = tile_bits(r3, r1);
+    p.in_jstride = 1;
+    p.in_tstride = R2 * R3;
+    p.out_jstride = R1 * R2;
+    p.out_tstride = 1;
+    p.bdiv = R2;
+    p.in_hi = (R2 * R3) << p.logT;
+    p.in_lo = R3;
+    p.out_hi = 1u << p.logT;
+    p.out_lo = R1;
+    p.tw_scale = 0;
+    p.load_j_fast = 1;
+    pl.grid_c = (R1 >> p.logT) * R2;
+  }
+  return pl;
+}
+
 static zg16_status get_domain(zg16_ctx* ctx, unsigned log_n, NttDomain** out) {
   auto it = ctx->domains.find(log_n);
   if (it != ctx->domains.end()) {
@@ -226,22 +312,34 @@ static zg16_status get_domain(zg16_ctx* ctx, unsigned log_n, NttDomain** out) {
   if (log_n >= 28) return fail(ctx, ZG16_ERR_POLYNOMIAL_DEGREE_TOO_LARGE, "domain 2^%u exceeds 2^27", log_n);
   NttDomain* d = new NttDomain();
   d->log_n = log_n;
+  d->plan = make_plan(log_n);
+  if (d->plan.r1 > MAX_RADIX_BITS) {
+    delete d;
+    return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "2^%u does not split into three radix-2^%u passes", log_n, max_radix_bits());
+  }
   const size_t N = (size_t)1 << log_n;
-  const size_t bytes29 = (4 * N + 2 * 512) * sizeof(Fr29), bytes = bytes29 + (2 * N + 512) * sizeof(Fr);
+  const size_t n_tw = (d->plan.r1 ? 2 : 0) + (d->plan.r2 ? 2 : 0);
+  const size_t bytes29 = ((2 + n_tw) * N + 2 * 512) * sizeof(Fr29), bytes = bytes29 + N * sizeof(Fr);
+  // staging that is released again: the exponent-indexed power tables the store-order tables are built from
+  const size_t stage_bytes = N * sizeof(Fr29) + (N + 512) * sizeof(Fr);
+  void* stage = nullptr;
   hipError_t e = hipMalloc(&d->block, bytes);
+  if (e == hipSuccess) e = hipMalloc(&stage, stage_bytes);
   if (e != hipSuccess) {
+    (void)hipFree(d->block);
     delete d;
     return fail(ctx, ZG16_ERR_OUT_OF_MEMORY, "hipMalloc of NTT tables failed: %s", hipGetErrorString(e));
   }
   Fr29* p = (Fr29*)d->block;
-  d->w[0] = p; p += N;
-  d->w[1] = p; p += N;
+  if (d->plan.r1) { d->tw_a[0] = p; p += N; d->tw_a[1] = p; p += N; }
+  if (d->plan.r2) { d->tw_b[0] = p; p += N; d->tw_b[1] = p; p += N; }
   d->gm = p; p += N;
   d->ginvm = p; p += N;
   d->w_small[0] = p; p += 512;
   d->w_small[1] = p; p += 512;
   d->g = (Fr*)((char*)d->block + bytes29);
-  Fr* tmp = d->g + N;  // N + 512 elements of staging, left unused afterwards
+  Fr29* w_full = (Fr29*)stage;
+  Fr* tmp = (Fr*)((char*)stage + N * sizeof(Fr29));
 
   Fr omega = host_root_of_unity();
   for (unsigned i = log_n; i < 28; i++) omega = sqr(omega);
@@ -261,14 +359,25 @@ static zg16_status get_domain(zg16_ctx* ctx, unsigned log_n, NttDomain** out) {
     launch(tmp, count, base, c);
     k_to_fr29<<<(unsigned)((count + 255) / 256), 256, 0, st>>>(tmp, dst, (uint32_t)count);
   };
-  table29(d->w[0], N, omega, one);
-  table29(d->w[1], N, omega_inv, one);
+  for (int dir = 0; dir < 2; dir++) {
+    if (!d->plan.r1) break;
+    table29(w_full, N, dir ? omega_inv : omega, one);
+    k_pass_twiddles<<<d->plan.grid_a, 256, 0, st>>>(d->plan.a, w_full, d->tw_a[dir]);
+    if (d->plan.r2) k_pass_twiddles<<<d->plan.grid_b, 256, 0, st>>>(d->plan.b, w_full, d->tw_b[dir]);
+  }
   table29(d->gm, N, g, d->minv);
   table29(d->ginvm, N, g_inv, d->minv);
   table29(d->w_small[0], 512, w1024, one);
   table29(d->w_small[1], 512, w1024_inv, one);
   launch(d->g, N, g, one);
-  ZG_HIP(ctx, hipGetLastError());
+  hipError_t le = hipGetLastError();
+  hipError_t se = hipStreamSynchronize(st);
+  (void)hipFree(stage);
+  if (le != hipSuccess || se != hipSuccess) {
+    (void)hipFree(d->block);
+    delete d;
+    return fail(ctx, ZG16_ERR_DEVICE, "building NTT tables failed: %s", hipGetErrorString(le != hipSuccess ? le : se));
+  }
   ctx->domains[log_n] = d;
   *out = d;
   return ZG16_OK;
@@ -282,20 +391,9 @@ void ntt_free_domains(zg16_ctx* ctx) {
   ctx->domains.clear();
 }
 
-static unsigned max_radix_bits() {
-  static unsigned v = 0;
-  if (!v) {
-    const char* e = getenv("ZG16_NTT_RADIX_BITS");
-    v = e ? (unsigned)atoi(e) : MAX_RADIX_BITS;
-    if (v < 2) v = 2;
-    if (v > MAX_RADIX_BITS) v = MAX_RADIX_BITS;
-  }
-  return v;
-}
-
 // Unnormalised transform: dst[i] = DFT_{w^+-1}(src)[i] * (post_scale ? post_scale[i] : 1).  dst may
 // alias src.  The factor rides on the last pass's store, so `ifft` followed by a coset scaling (or
-// `icoset_fft`'s trailing g^-i / m) costs one extra product per element and no extra pass.
+// `icoset_fft`'s trailing g^-i / m) costs no extra product and no extra pass.
 static zg16_status ntt_raw(zg16_ctx* ctx, NttDomain* d, const Fr* src, Fr* dst, bool inverse,
                            const Fr29* post_scale = nullptr) {
   const unsigned n = d->log_n;
@@ -304,71 +402,23 @@ static zg16_status ntt_raw(zg16_ctx* ctx, NttDomain* d, const Fr* src, Fr* dst, 
     if (post_scale) k_scale_const<<<1, 256, 0, ctx->stream>>>(dst, 1, d->minv);  // g^0 / m
     return ZG16_OK;
   }
-  const unsigned rb = max_radix_bits();
-  unsigned r1, r2, r3;
-  if (n <= rb) {
-    r1 = 0; r2 = 0; r3 = n;
-  } else if (n <= 2 * rb) {
-    r1 = (n + 1) / 2; r2 = 0; r3 = n - r1;
-  } else {
-    r1 = (n + 2) / 3; r2 = (n - r1 + 1) / 2; r3 = n - r1 - r2;
-  }
-  if (r1 > MAX_RADIX_BITS) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "2^%u does not split into three radix-2^%u passes", n, rb);
-  const uint32_t R1 = 1u << r1, R2 = 1u << r2, R3 = 1u << r3;
+  const NttPlan& pl = d->plan;
   const int dir = inverse ? 1 : 0;
   Fr* tmp = nullptr;
-  if (r1) ZG_TRY(scratch_get(ctx, 0, sizeof(Fr) << n, (void**)&tmp));
+  if (pl.r1) ZG_TRY(scratch_get(ctx, 0, sizeof(Fr) << n, (void**)&tmp));
   hipStream_t st = ctx->stream;
-  auto tile_bits = [](unsigned rbits, unsigned limit_bits) {
-    unsigned t = 10 - rbits;  // TILE_ELEMS / R
-    return t < limit_bits ? t : limit_bits;
-  };
-  if (r1) {  // pass A: over i1, tile of adjacent (i2,i3)
-    PassParams p = {};
-    p.logR = r1;
-    p.logT = tile_bits(r1, r2 + r3);
-    p.in_jstride = p.out_jstride = R2 * R3;
-    p.in_tstride = p.out_tstride = 1;
-    p.bdiv = 0x80000000u;
-    p.in_lo = p.out_lo = p.tw_lo_mul = 1u << p.logT;
-    p.tw_scale = 1;
-    const uint32_t grid = (R2 * R3) >> p.logT;
-    KernelTimer kt(ctx, K_NTT_PASS, 64.0 * (double)((size_t)1 << n));
-    k_ntt_pass<<<grid, 256, 0, st>>>(src, tmp, p, d->w_small[dir], d->w[dir], nullptr);
+  const double bytes = 64.0 * (double)((size_t)1 << n);
+  if (pl.r1) {
+    KernelTimer kt(ctx, K_NTT_PASS, bytes);
+    k_ntt_pass<<<pl.grid_a, 256, 0, st>>>(src, tmp, pl.a, d->w_small[dir], d->tw_a[dir]);
   }
-  if (r2) {  // pass B: over i2, tile of adjacent i3, one k1 per block row
-    PassParams p = {};
-    p.logR = r2;
-    p.logT = tile_bits(r2, r3);
-    p.in_jstride = p.out_jstride = R3;
-    p.in_tstride = p.out_tstride = 1;
-    p.bdiv = R3 >> p.logT;
-    p.in_hi = p.out_hi = R2 * R3;
-    p.in_lo = p.out_lo = p.tw_lo_mul = 1u << p.logT;
-    p.tw_scale = R1;
-    const uint32_t grid = R1 * (R3 >> p.logT);
-    KernelTimer kt(ctx, K_NTT_PASS, 64.0 * (double)((size_t)1 << n));
-    k_ntt_pass<<<grid, 256, 0, st>>>(tmp, tmp, p, d->w_small[dir], d->w[dir], nullptr);
+  if (pl.r2) {
+    KernelTimer kt(ctx, K_NTT_PASS, bytes);
+    k_ntt_pass<<<pl.grid_b, 256, 0, st>>>(tmp, tmp, pl.b, d->w_small[dir], d->tw_b[dir]);
   }
-  {  // pass C: over i3 (contiguous), tile of adjacent k1, scatter to natural order
-    PassParams p = {};
-    p.logR = r3;
-    p.logT = tile_bits(r3, r1);
-    p.in_jstride = 1;
-    p.in_tstride = R2 * R3;
-    p.out_jstride = R1 * R2;
-    p.out_tstride = 1;
-    p.bdiv = R2;
-    p.in_hi = (R2 * R3) << p.logT;
-    p.in_lo = R3;
-    p.out_hi = 1u << p.logT;
-    p.out_lo = R1;
-    p.tw_scale = 0;
-    p.load_j_fast = 1;
-    p.post_scale = post_scale ? 1 : 0;
-    const uint32_t grid = (R1 >> p.logT) * R2;
-    KernelTimer kt(ctx, K_NTT_PASS, 64.0 * (double)((size_t)1 << n));
-    k_ntt_pass<<<grid, 256, 0, st>>>(r1 ? tmp : src, dst, p, d->w_small[dir], d->w[dir], post_scale);
+  {
+    KernelTimer kt(ctx, K_NTT_PASS, bytes);
+    k_ntt_pass<<<pl.grid_c, 256, 0, st>>>(pl.r1 ? tmp : src, dst, pl.c, d->w_small[dir], post_scale);
   }
   ZG_HIP(ctx, hipGetLastError());
   return ZG16_OK;
