@@ -352,7 +352,10 @@ static zg16_status prove_partial_impl(zg16_ctx* ctx, const zg16_pk* pk, const zg
   // Stage boundaries are events; nothing below waits on the host until every kernel is enqueued.
   enum { E_BEGIN, E_Z, E_SPMV, E_NTT, E_G1, E_G2_BEGIN, E_G2_END, E_END, E_Z_END = 14 };
   hipEvent_t* ev = ctx->ev;
-  hipStream_t st = ctx->stream, aux = ctx->aux_stream;
+  // ZG16_SERIAL=1 puts every stage on the main stream: slower, but per-kernel timings are then free of
+  // contention between the pipelines (used for the uncontended roofline figures)
+  static const bool serial = getenv("ZG16_SERIAL") && atoi(getenv("ZG16_SERIAL")) != 0;
+  hipStream_t st = ctx->stream, aux = serial ? st : ctx->aux_stream;
   const size_t m = (size_t)1 << r->log_m;
   const uint32_t tc = pk->table_c;
   auto stride = [&](size_t lo, size_t hi) { return tc ? hi - lo : (size_t)0; };
@@ -396,7 +399,7 @@ static zg16_status prove_partial_impl(zg16_ctx* ctx, const zg16_pk* pk, const zg
     ZG_HIP(ctx, hipEventRecord(ev[E_G2_END], aux));
   }
   if (tables) {
-    hipStream_t early = ctx->early_stream;
+    hipStream_t early = serial ? st : ctx->early_stream;
     ZG_HIP(ctx, hipStreamWaitEvent(early, ev[E_Z], 0));
     const MsmStreams ms = {early, nullptr, nullptr, nullptr};
     ZG_TRY(msm_launch<Fq>(ctx, ms, 6, pinned + 2 * MSM_PINNED_BYTES, jobs_z, 3, 3, &pend_z));
@@ -410,7 +413,7 @@ static zg16_status prove_partial_impl(zg16_ctx* ctx, const zg16_pk* pk, const zg
 
   G1XYZZ g1[3];
   if (tables) {
-    const MsmStreams ms = {st, ctx->side_stream, ev[8], ev[9]};
+    const MsmStreams ms = {st, serial ? nullptr : ctx->side_stream, ev[8], ev[9]};
     ZG_TRY(msm_launch<Fq>(ctx, ms, 1, pinned, &job_h, 1, 1, &pend_h));
     ZG_HIP(ctx, hipEventRecord(ev[E_G1], st));
     ZG_HIP(ctx, hipStreamWaitEvent(st, ev[E_Z_END], 0));
