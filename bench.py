@@ -42,32 +42,37 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-rows", type=int, default=20)
     ap.add_argument("--dense", action="store_true", help="all aux values uniform (multiexp worst case)")
-    ap.add_argument("--cpu-log-rows", type=int, default=16, help="circuit size of the CPU-baseline sample")
+    ap.add_argument("--cpu-log-rows", type=int, default=20, help="circuit size of the CPU-baseline sample (2^20: seconds of CPU work on all host cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--split-transforms", choices=("auto", "on", "off"), default="auto",
                     help="run the A/B/C transform chains on different ranks (auto: 3+ ranks and 2^22+ rows)")
     return ap.parse_args()
 
 
-def cpu_baseline_leg(ctx, log_rows, dense):
+def cpu_baseline_leg(ctx, log_rows, dense, reuse=None):
     """Time the CPU restatement of the bellman prover on a bounded sample of the same workload and
-    check that the GPU produces the identical proof for it.  The only place this file touches oracle/."""
+    check that the GPU produces the identical proof for it.  The only place this file touches oracle/.
+    reuse: (params, r1cs, z_in, z_aux, key, mat) of the benchmark itself when the sample is the whole workload."""
     from oracle import cpu_binding as cb
     from zinc_amd import workload
     from zinc_amd.groth16 import prove_recorded
     from zinc_amd.fields import ints_to_mont, R_MOD
-    circ = workload.SyntheticCircuit(1 << log_rows, dense=dense)
-    params = workload.generate_parameters(ctx, circ, TOXIC)
-    r1cs = circ.r1cs()
-    zi, za = circ.witness()
+    if reuse:
+        params, r1cs, zi, za, key, mat = reuse
+    else:
+        circ = workload.SyntheticCircuit(1 << log_rows, dense=dense)
+        params = workload.generate_parameters(ctx, circ, TOXIC)
+        r1cs = circ.r1cs()
+        zi, za = circ.witness()
+        key, mat = params.upload(ctx), r1cs.upload(ctx)
     rs = ints_to_mont([pow(7, 123456789, R_MOD), pow(5, 987654321, R_MOD)], R_MOD)
     threads = min(cb.hardware_threads() or 1, int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or 1 << 30)
     st, cpu_proof, tm = cb.prove(params, r1cs, zi, za, rs[0], rs[1], threads)
     assert st == 0, "CPU baseline prover failed with status %d" % st
-    key, mat = params.upload(ctx), r1cs.upload(ctx)
     gpu = prove_recorded(ctx, key, mat, zi, za, rs[0], rs[1])
-    key.free()
-    mat.free()
+    if not reuse:
+        key.free()
+        mat.free()
     same = all(np.array_equal(np.frombuffer(bytes(g), dtype=np.uint64), c)
                for g, c in zip((gpu.raw.a, gpu.raw.b, gpu.raw.c), cpu_proof))
     return {"value": tm["total_s"], "unit": "s", "cores": threads, "kind": "port",
@@ -225,7 +230,12 @@ def main():
         if g1[0]:
             out["msm_g1_accumulate_points_per_s"] = g1[2] / (g1[0] * 1e-3)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_leg(ctx, args.cpu_log_rows, args.dense)
+            cpu_rows = min(args.cpu_log_rows, args.log_rows)
+            args.cpu_log_rows = cpu_rows
+            reuse = (params, r1cs, zi, za, key, mat) if cpu_rows == args.log_rows else None
+            out["cpu_baseline"] = cpu_baseline_leg(ctx, cpu_rows, args.dense, reuse)
+            out["cpu_baseline"]["gpu_over_cpu_latency"] = (out["cpu_baseline"]["value"] / (ms_per_step / 1e3)
+                                                           if cpu_rows == args.log_rows else None)
             out["cpu_baseline"]["sample"] = out["cpu_baseline"]["sample"].replace(
                 "(1/1 of", "(1/%d of" % (1 << (args.log_rows - args.cpu_log_rows)))
         print(json.dumps(out), flush=True)
