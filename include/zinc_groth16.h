@@ -111,6 +111,16 @@ zg16_status zg16_ctx_set_stream(zg16_ctx* ctx, void* hip_stream);
 zg16_status zg16_pk_upload(zg16_ctx* ctx, const zg16_pk_view* view, int shard_index,
                            int shard_count, zg16_pk** out);
 void        zg16_pk_free(zg16_pk* pk);
+/* The same from the bytes `Parameters::<Bn256>::write` produces -- the proving-key file that
+ * `zvm prove` opens with `Parameters::read(file, checked = true)`
+ * (zinc-vm/src/zvm/arguments/command/prove.rs:73-76; written at setup.rs:67-69).  The points are decoded,
+ * converted to Montgomery form and (with `checked`) validated on the GPU: on the curve, in the prime-order
+ * subgroup (G2: multiplication by r), no point at infinity in a query vector.  Any violation or a
+ * truncated file gives ZG16_ERR_MALFORMED_KEY.  zg16_pk_vk_view fills a view with the handle's
+ * verifying-key points (host memory owned by the handle) for zg16_prove_finish. */
+zg16_status zg16_pk_upload_bytes(zg16_ctx* ctx, const uint8_t* data, size_t len, int checked,
+                                 int shard_index, int shard_count, zg16_pk** out);
+zg16_status zg16_pk_vk_view(const zg16_pk* pk, zg16_pk_view* out);
 
 /* ---- constraint matrices ------------------------------------------------------------------ */
 /* Upload A, B, C once per circuit; the structure does not depend on the witness.  Computes the

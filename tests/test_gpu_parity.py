@@ -285,6 +285,61 @@ def test_prove_golden(gpu_ctx, idx):
     assert codec.proof_write(proof.as_tuple()).hex() == fx["proof_bytes"]
 
 
+@pytest.mark.parametrize("idx", [1, 3])
+def test_key_file_decoded_on_gpu(gpu_ctx, idx):
+    """`Parameters::read(file, checked = true)` on the GPU: the key bytes the codec writes decode to a key
+    whose proof is the golden one; damaged files are rejected the way upstream's reader rejects them."""
+    from zinc_amd import codec
+    from zinc_amd.groth16 import DeviceKey
+    fx = golden("prove_tiny_%d.json" % idx)
+    circ, key = FixtureCircuit(fx), FixtureKey(fx)
+    data = codec.params_write(key)
+    pa = ProvingAssignment()
+    pa.alloc_input(1)
+    circ.synthesize(pa)
+    pa.finalize_inputs()
+    mat = pa.r1cs().upload(gpu_ctx)
+    zi, za = pa.witness()
+    rs = ints_to_mont([int(fx["r"], 16), int(fx["s"], 16)], R_MOD)
+    for checked in (True, False):
+        dev = DeviceKey.from_bytes(gpu_ctx, data, checked=checked)
+        assert prove_recorded(gpu_ctx, dev, mat, zi, za, rs[0], rs[1]).as_tuple() == fixture_proof(fx)
+        dev.free()
+    mat.free()
+
+    def rejected(blob, checked=True):
+        with pytest.raises(SynthesisError) as e:
+            DeviceKey.from_bytes(gpu_ctx, blob, checked=checked)
+        return e.value.status_name == "MalformedKey"
+
+    vk_len = len(codec.vk_write(key))
+    h0 = vk_len + 4  # first point of h
+    bad = bytearray(data); bad[h0 + 63] ^= 1                      # y of h[0] off the curve
+    assert rejected(bad)
+    DeviceKey.from_bytes(gpu_ctx, bytes(bad), checked=False).free()   # unchecked accepts it, as upstream does
+    bad = bytearray(data); bad[h0:h0 + 64] = bytes([0x40]) + bytes(63)  # infinity inside a query vector
+    assert rejected(bad)
+    bad = bytearray(data); bad[h0] |= 0x80                        # compression flag on an uncompressed point
+    assert rejected(bad)
+    bad = bytearray(data); bad[h0:h0 + 32] = (codec.Q_MOD).to_bytes(32, "big")   # x = q is not a field element
+    assert rejected(bad)
+    assert rejected(data[:-1]) and rejected(data[:vk_len + 2]) and rejected(data[:10])
+    # a point on the twist that is not in the prime-order subgroup, in place of b_g2[0]
+    x = (5, 1)
+    while True:
+        rhs = codec._fq2_mul(codec._fq2_mul(x, x), x)
+        y = codec._fq2_sqrt(((rhs[0] + codec.B_G2[0]) % Q_MOD, (rhs[1] + codec.B_G2[1]) % Q_MOD))
+        if y is not None:
+            break
+        x = (x[0] + 1, 1)
+    off = len(data) - 128 * len(key.b_g2)
+    bad = bytearray(data); bad[off:off + 128] = codec.g2_write((x, y), False)
+    assert rejected(bad)
+    # alpha_g1 (a verifying-key point) may be anything on the curve, but not off it
+    bad = bytearray(data); bad[63] ^= 1
+    assert rejected(bad)
+
+
 @pytest.mark.parametrize("log_rows,dense", [(10, False), (12, True), (14, False), (16, False)])
 def test_prove_vs_cpu_oracle(gpu_ctx, log_rows, dense):
     """Seeded zinc-shaped circuits: GPU proof == proof of the CPU restatement of bellman, bit for bit."""

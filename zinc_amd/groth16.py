@@ -204,9 +204,25 @@ class DeviceKey:
     def __init__(self, ctx, params, shard_index=0, shard_count=1):
         self.ctx, self.params = ctx, params
         self.handle = C.c_void_p()
+        if params is None:
+            return
         v = params.view()
         _check(ctx.handle, ctx._lib.zg16_pk_upload(ctx.handle, C.byref(v), shard_index, shard_count,
                                                    C.byref(self.handle)))
+
+    @classmethod
+    def from_bytes(cls, ctx, data, checked=True, shard_index=0, shard_count=1):
+        """bellman `Parameters::read(reader, checked)` on the GPU: `data` is the proving-key file."""
+        key = cls(ctx, None)
+        data = bytes(data)
+        _check(ctx.handle, ctx._lib.zg16_pk_upload_bytes(ctx.handle, data, len(data), int(checked), shard_index,
+                                                         shard_count, C.byref(key.handle)))
+        return key
+
+    def vk_view(self):
+        v = _lib.PkView()
+        _check(self.ctx.handle, self.ctx._lib.zg16_pk_vk_view(self.handle, C.byref(v)))
+        return v
 
     def free(self):
         if self.handle:

@@ -67,6 +67,9 @@ SYMBOLS = [
     ("zg16_ctx_set_stream", C.c_int, [C.c_void_p, C.c_void_p]),
     ("zg16_pk_upload", C.c_int, [C.c_void_p, C.POINTER(PkView), C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     ("zg16_pk_free", None, [C.c_void_p]),
+    ("zg16_pk_upload_bytes", C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
+                                       C.POINTER(C.c_void_p)]),
+    ("zg16_pk_vk_view", C.c_int, [C.c_void_p, C.POINTER(PkView)]),
     ("zg16_r1cs_upload", C.c_int, [C.c_void_p, C.POINTER(R1csView), C.POINTER(C.c_void_p)]),
     ("zg16_r1cs_free", None, [C.c_void_p]),
     ("zg16_r1cs_density", C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
