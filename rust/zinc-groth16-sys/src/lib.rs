@@ -41,6 +41,10 @@ extern "C" {
     pub fn zg16_r1cs_free(r: *mut zg16_r1cs);
     pub fn zg16_prove(ctx: *mut zg16_ctx, pk: *const zg16_pk, r1cs: *const zg16_r1cs, z_in: *const c_void, z_aux: *const c_void,
                       witness_on_device: c_int, r: *const u64, s: *const u64, out: *mut zg16_proof) -> c_int;
+    /// `Parameters::<Bn256>::read(file, checked)` on the GPU: `data` is the proving-key file
+    /// (zinc-vm/src/zvm/arguments/command/prove.rs:73-76).
+    pub fn zg16_pk_upload_bytes(ctx: *mut zg16_ctx, data: *const u8, len: usize, checked: c_int,
+                                shard_index: c_int, shard_count: c_int, out: *mut *mut zg16_pk) -> c_int;
 }
 
 /// Plays the role of bellman's `ProvingAssignment`, but records the matrices instead of evaluating
