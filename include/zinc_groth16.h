@@ -138,6 +138,10 @@ zg16_status zg16_prove(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1cs* r1cs,
                        const uint64_t* z_in, const uint64_t* z_aux, int witness_on_device,
                        const uint64_t r[4], const uint64_t s[4], zg16_proof* out);
 
+/* bellman `Proof::write`: the 128 bytes whose hex `zvm prove` prints
+ * (zinc-vm/src/zvm/arguments/command/prove.rs:171-174).  Host arithmetic only. */
+zg16_status zg16_proof_encode(const zg16_proof* proof, uint8_t out[128]);
+
 /* Multi-GPU form: every rank calls zg16_prove_partial with its key shard (and the full
  * witness); the partials are gathered (RCCL all_gather / host copy) and any one rank calls
  * zg16_prove_finish on the full list.  The vk points come from the same zg16_pk_view. */

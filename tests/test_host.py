@@ -180,3 +180,31 @@ def test_fp29_constants_in_sync(tmp_path):
             assert val(l) == k * q, name
             lend = 30 if name.startswith("KS") else 31
             assert all(v >= (1 << lend) - (1 << (lend - 29)) for v in l[:8]) and all(0 <= v < 1 << 32 for v in l)
+
+
+def test_proof_encode_matches_codec_and_fixtures():
+    """zg16_proof_encode (C, host-only) == the Python codec == the proof bytes recorded in the fixtures."""
+    from zinc_amd.fields import g1_to_mont, g2_to_mont
+    L = zlib.load()
+    for idx in (1, 2, 3):
+        fx = golden("prove_tiny_%d.json" % idx)
+        a, b, c = fixture_proof(fx)
+        raw = zlib.Proof()
+        C.memmove(raw.a, g1_to_mont([a]).ctypes.data, 64)
+        C.memmove(raw.b, g2_to_mont([b]).ctypes.data, 128)
+        C.memmove(raw.c, g1_to_mont([c]).ctypes.data, 64)
+        out = (C.c_uint8 * 128)()
+        assert L.zg16_proof_encode(C.byref(raw), out) == 0
+        assert bytes(out).hex() == fx["proof_bytes"] == codec.proof_write((a, b, c)).hex()
+    # negated points flip the sign bit; the identity sets bit 6
+    fx = golden("prove_tiny_1.json")
+    a, b, c = fixture_proof(fx)
+    from zinc_amd.fields import Q_MOD
+    na = (a[0], (-a[1]) % Q_MOD)
+    nb = (b[0], ((-b[1][0]) % Q_MOD, (-b[1][1]) % Q_MOD))
+    raw = zlib.Proof()
+    C.memmove(raw.a, g1_to_mont([na]).ctypes.data, 64)
+    C.memmove(raw.b, g2_to_mont([nb]).ctypes.data, 128)
+    out = (C.c_uint8 * 128)()
+    assert L.zg16_proof_encode(C.byref(raw), out) == 0
+    assert bytes(out).hex() == codec.proof_write((na, nb, None)).hex()

@@ -244,6 +244,54 @@ zg16_status zg16_pk_upload_bytes(zg16_ctx* ctx, const uint8_t* data, size_t len,
   return ZG16_OK;
 }
 
+// 32 big-endian bytes of the canonical value of a Montgomery Fq
+static void write_fq(const Fq& m, uint8_t* b) {
+  const Fq x = from_mont(m);
+  for (int i = 0; i < 8; i++) {
+    uint8_t* p = b + 28 - 4 * i;
+    p[0] = (uint8_t)(x.v[i] >> 24); p[1] = (uint8_t)(x.v[i] >> 16); p[2] = (uint8_t)(x.v[i] >> 8); p[3] = (uint8_t)x.v[i];
+  }
+}
+// is the canonical value of a greater than that of b (both Montgomery)?
+static bool fq_gt(const Fq& a, const Fq& b) {
+  const Fq x = from_mont(a), y = from_mont(b);
+  for (int i = 7; i >= 0; i--)
+    if (x.v[i] != y.v[i]) return x.v[i] > y.v[i];
+  return false;
+}
+
+// bellman `Proof::write` (zinc-vm/src/zvm/arguments/command/prove.rs:171-174): A, B, C in pairing_ce's
+// compressed encoding -- x big-endian (G2: c1 then c0), bit 7 of byte 0 set when y is the larger of
+// (y, -y) (Fq2 compared by c1, then c0), bit 6 for the point at infinity.
+zg16_status zg16_proof_encode(const zg16_proof* proof, uint8_t out[128]) {
+  if (!proof || !out) return ZG16_ERR_INVALID_ARGUMENT;
+  memset(out, 0, 128);
+  auto g1 = [](const uint64_t* limbs, uint8_t* dst) {
+    G1Affine p;
+    memcpy(&p, limbs, sizeof p);
+    if (p.is_inf()) { dst[0] = 0x40; return; }
+    write_fq(p.x, dst);
+    if (fq_gt(p.y, neg(p.y))) dst[0] |= 0x80;
+  };
+  g1(proof->a, out);
+  {
+    G2Affine p;
+    memcpy(&p, proof->b, sizeof p);
+    uint8_t* dst = out + 32;
+    if (p.is_inf()) {
+      dst[0] = 0x40;
+    } else {
+      write_fq(p.x.c1, dst);
+      write_fq(p.x.c0, dst + 32);
+      const Fq2 ny = neg(p.y);
+      const bool larger = p.y.c1 != ny.c1 ? fq_gt(p.y.c1, ny.c1) : fq_gt(p.y.c0, ny.c0);
+      if (larger) dst[0] |= 0x80;
+    }
+  }
+  g1(proof->c, out + 96);
+  return ZG16_OK;
+}
+
 // The verifying-key points a key handle holds, as a view for zg16_prove_finish (query fields stay null).
 zg16_status zg16_pk_vk_view(const zg16_pk* pk, zg16_pk_view* out) {
   if (!pk || !out) return ZG16_ERR_INVALID_ARGUMENT;

@@ -77,6 +77,7 @@ SYMBOLS = [
                              u64p, u64p, C.POINTER(Proof)]),
     ("zg16_prove_partial", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                      C.POINTER(Partial)]),
+    ("zg16_proof_encode", C.c_int, [C.POINTER(Proof), C.POINTER(C.c_uint8)]),
     ("zg16_eval_chain", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     ("zg16_h_from_cosets", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint]),
     ("zg16_prove_partial_h", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
