@@ -313,17 +313,25 @@ struct Assembly {
   Fr rc, sc;  // canonical r, s
   G1XYZZ A, c_part;
   G2XYZZ B;
-  void early(const G1XYZZ& qa, const G1XYZZ& qb1, const G2XYZZ& qb2) {
+  // needs nothing from the GPU: alpha + r*delta and beta + s*delta
+  void key_terms() {
     A = scalar_mul_w4(G1XYZZ::from_affine(delta1), rc.v);
     add_mixed(A, alpha1);
-    add_full(A, qa);
     B = scalar_mul_w4(G2XYZZ::from_affine(delta2), sc.v);
     add_mixed(B, beta2);
-    add_full(B, qb2);
+  }
+  void with_g2(const G2XYZZ& qb2) { add_full(B, qb2); }
+  void with_g1(const G1XYZZ& qa, const G1XYZZ& qb1) {
+    add_full(A, qa);
     G1XYZZ b1 = qb1;
     add_mixed(b1, beta1);
     c_part = scalar_mul_w4(A, sc.v);
     add_full(c_part, scalar_mul_w4(b1, rc.v));
+  }
+  void early(const G1XYZZ& qa, const G1XYZZ& qb1, const G2XYZZ& qb2) {
+    key_terms();
+    with_g2(qb2);
+    with_g1(qa, qb1);
   }
   void finish(const G1XYZZ& hl, zg16_proof* out) const {
     G1XYZZ C = c_part;
@@ -430,11 +438,13 @@ static zg16_status prove_partial_impl(zg16_ctx* ctx, const zg16_pk* pk, const zg
   G2XYZZ qb2;
   bool early_done = false;
   if (tables && early) {
+    early->key_terms();  // host work while the GPU is busy
     ZG_HIP(ctx, hipEventSynchronize(ev[E_Z_END]));
-    ZG_HIP(ctx, hipEventSynchronize(ev[E_G2_END]));
     ZG_TRY(msm_collect<Fq>(ctx, &pend_z, g1));
+    early->with_g1(g1[1], g1[2]);
+    ZG_HIP(ctx, hipEventSynchronize(ev[E_G2_END]));
     ZG_TRY(msm_collect<Fq2>(ctx, &pend_g2, &qb2));
-    early->early(g1[1], g1[2], qb2);
+    early->with_g2(qb2);
     early_done = true;
   }
   ZG_HIP(ctx, hipEventSynchronize(ev[E_END]));

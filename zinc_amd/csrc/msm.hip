@@ -112,7 +112,7 @@ ZG_D uint32_t extract_bits(const uint32_t* v, uint32_t lo, uint32_t c) {
 //                   their buckets are counted / ranked in LDS and again cost one global atomic per
 //                   (tile, bucket).  A tile that spans more buckets than LDS holds (tiny multiexps)
 //                   falls back to one atomic per entry.
-static constexpr uint32_t SORT_TERMS = 16;          // terms per lane in k_sort_count / k_sort_scatter
+static constexpr uint32_t SORT_TERMS = 4;           // terms per lane in k_sort_count / k_sort_scatter
 static constexpr uint32_t SORT_MAX_COARSE = 1024;
 static constexpr uint32_t FINE_TILE = 4096;         // entries per workgroup in k_fine_*
 static constexpr uint32_t FINE_PER_LANE = FINE_TILE / 256;
