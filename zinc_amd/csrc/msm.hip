@@ -18,12 +18,12 @@
 //                          counting sort of the (bucket, window, base index, sign) entries
 //   2. k_scan_*          : exclusive scan of bucket sizes -> bucket offsets
 //   3. k_accumulate      : segmented reduction over the sorted entries.  Every lane owns a fixed
-//                          chunk of 64 consecutive entries whatever the bucket sizes are, so a
+//                          chunk of consecutive entries whatever the bucket sizes are, so a
 //                          skewed witness (zinc witnesses are mostly 0/1 bits) cannot unbalance
 //                          the launch.  A run inside one chunk finishes its bucket; a run cut by a
 //                          chunk edge leaves a partial sum in slot 2t / 2t+1.
-//   4. k_combine         : eight lanes per bucket add that bucket's partials (buckets spanning at
-//                          most 32 chunks) and fold by shuffles; larger buckets get one workgroup
+//   4. k_combine         : four lanes per bucket add the pieces of a bucket cut at chunk edges (at
+//                          most 32 of them) and fold by shuffles; larger buckets get one workgroup
 //                          each in k_heavy.
 //   5. k_sum_range       : plain tree sum for scalars equal to one (about half of a zinc witness);
 //                          they reach their bucket through a wave-aggregated counter, not a digit.
@@ -36,7 +36,7 @@
 namespace zg {
 
 static constexpr uint32_t ACC_KMIN = 8;   // fewest entries a lane of k_accumulate takes
-static constexpr int LIGHT_SLOTS = 64;    // buckets whose partials span at most this many slots: k_combine
+static constexpr uint32_t LIGHT_PIECES = 32;  // buckets cut into at most this many pieces: k_combine, more: k_heavy
 static constexpr int MAX_JOBS = 4;
 static constexpr uint32_t KEY_INVALID = 0xffffffffu;
 static constexpr uint32_t KEY_MASK = 0x00ffffffu;  // level-0 keys carry the window in the top byte
@@ -383,9 +383,13 @@ ZG_D uint32_t chunk_len(uint32_t entries, uint32_t lanes) {
   return k < ACC_KMIN ? ACC_KMIN : k;
 }
 
-// k_combine owns the buckets whose partial slots span at most LIGHT_SLOTS; k_heavy owns the rest.
-ZG_D bool bucket_is_light(uint32_t s, uint32_t e, uint32_t K) {
-  return 2 * ((e - 1) / K - s / K + 1) <= (uint32_t)LIGHT_SLOTS;
+// A bucket [s, e) of the sorted list that level 0 cut at chunk edges has one partial sum per chunk it
+// touches: piece 0 in the first chunk's tail slot (head slot if the bucket starts the chunk -- it is
+// then that chunk's first run), every later piece in its chunk's head slot.
+ZG_D uint32_t piece_slot(uint32_t s, uint32_t K, uint32_t piece) {
+  const uint32_t cf = s / K;
+  if (piece == 0) return 2 * cf + (s % K != 0);
+  return 2 * (cf + piece);
 }
 
 // Level 0 of the segmented reduction: logical thread t owns sorted entries [K t, K t + K) whatever
@@ -396,7 +400,6 @@ template <class F>
 __global__ __launch_bounds__(256, kMinWaves<F>) void k_accumulate(JobTable<F> jt, uint32_t nb, uint32_t lanes,
                                                                   const uint2* __restrict__ rec,
                                                                   const uint32_t* __restrict__ off,
-                                                                  uint32_t* __restrict__ keys_out,
                                                                   typename MsmOps<F>::PtMem* __restrict__ pts_out,
                                                                   typename MsmOps<F>::PtMem* __restrict__ bucket_sum,
                                                                   uint32_t* __restrict__ err_flag) {
@@ -411,14 +414,12 @@ __global__ __launch_bounds__(256, kMinWaves<F>) void k_accumulate(JobTable<F> jt
   uint32_t cur = KEY_INVALID;
   typename O::Pt acc = O::inf();
   bool first_run = true;
-  uint32_t out_key[2] = {KEY_INVALID, KEY_INVALID};
 
   auto flush = [&]() {
     if (off[cur] >= lo && off[cur + 1] <= hi) {
       O::store(bucket_sum + cur, acc);
     } else {
       const int slot = first_run ? 0 : 1;  // a cut run is the first or (otherwise) the last of its chunk
-      out_key[slot] = cur;
       O::store(pts_out + (2 * (size_t)t + slot), acc);
     }
     first_run = false;
@@ -440,19 +441,14 @@ __global__ __launch_bounds__(256, kMinWaves<F>) void k_accumulate(JobTable<F> jt
       *err_flag = 1;  // identity base consumed by a non-zero scalar
   }
   if (cur != KEY_INVALID) flush();
-  if ((threadIdx.x % O::LP) == 0) {
-    keys_out[2 * (size_t)t] = out_key[0];
-    keys_out[2 * (size_t)t + 1] = out_key[1];
-  }
 }
 
-// L adjacent logical threads per bucket add the partial sums level 0 left for a bucket it cut into a
-// few pieces (one valid partial per chunk the bucket touches), then fold across the threads by
-// shuffles.  Buckets spanning more than LIGHT_SLOTS slots are appended to heavy_list for k_heavy.
+// L adjacent logical threads per bucket add the pieces level 0 left of a bucket it cut at chunk edges,
+// then fold across the threads by shuffles.  Buckets in more than LIGHT_PIECES pieces are appended to
+// heavy_list for k_heavy.
 template <class F, int L>
 __global__ __launch_bounds__(256, kMinWaves<F>) void k_combine(uint32_t nb, uint32_t lanes,
                                                                  const uint32_t* __restrict__ off,
-                                                                 const uint32_t* __restrict__ keys1,
                                                                  const typename MsmOps<F>::PtMem* __restrict__ pts1,
                                                                  typename MsmOps<F>::PtMem* __restrict__ bucket_sum,
                                                                  uint32_t* __restrict__ heavy_count,
@@ -461,34 +457,31 @@ __global__ __launch_bounds__(256, kMinWaves<F>) void k_combine(uint32_t nb, uint
   const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) / O::LP;
   const uint32_t b = t / L, sub = t % L;
   const uint32_t K = chunk_len(off[nb], lanes);
-  uint32_t lo = 0, hi = 0;  // slot range this bucket's threads share; empty when there is nothing to add
+  uint32_t s = 0, pieces = 0;  // pieces == 0: nothing to add here
   if (b < nb) {
-    const uint32_t s = off[b], e = off[b + 1];
+    s = off[b];
+    const uint32_t e = off[b + 1];
     if (e > s) {
-      const uint32_t cf = s / K, cl = (e - 1) / K;
-      if (cf != cl) {  // otherwise level 0 finished it inside one chunk
-        if (bucket_is_light(s, e, K)) {
-          lo = 2 * cf;
-          hi = 2 * cl + 1;  // in its last chunk the bucket is the first run: head slot
-        } else if (sub == 0 && (threadIdx.x % O::LP) == 0) {
-          heavy_list[atomicAdd(heavy_count, 1u)] = b;
-        }
+      const uint32_t n = (e - 1) / K - s / K + 1;
+      if (n > LIGHT_PIECES) {
+        if (sub == 0 && (threadIdx.x % O::LP) == 0) heavy_list[atomicAdd(heavy_count, 1u)] = b;
+      } else if (n > 1) {  // n == 1: level 0 finished the bucket inside one chunk
+        pieces = n;
       }
     }
   }
   typename O::Pt acc = O::inf();
-  for (uint32_t i = lo + sub; i < hi; i += L)
-    if (keys1[i] == b) O::add(acc, O::load(pts1 + i));
+  for (uint32_t p = sub; p < pieces; p += L) O::add(acc, O::load(pts1 + piece_slot(s, K, p)));
   if (L > 1) {
     // the threads of one bucket are adjacent in the wave and all of them reach this point
-    if (__ballot(hi > lo) != 0) {
+    if (__ballot(pieces != 0) != 0) {
       for (int d = L / 2; d >= 1; d >>= 1) {
         const typename O::Pt o = O::shfl_down(acc, d * O::LP);
         if (sub + d < L) O::add(acc, o);
       }
     }
   }
-  if (hi > lo && sub == 0) O::store(bucket_sum + b, acc);
+  if (pieces && sub == 0) O::store(bucket_sum + b, acc);
 }
 
 // p * k for a small unsigned k
@@ -518,12 +511,12 @@ ZG_D void block_sum(typename MsmOps<F>::Pt& total, typename MsmOps<F>::Pt* sh /*
 }
 
 // One workgroup per heavy bucket (grid-stride over heavy_list): logical threads stride over the
-// bucket's partial slots, then the workgroup tree-adds through LDS.
+// bucket's pieces, then the workgroup tree-adds through LDS.
 template <class F>
 __global__ __launch_bounds__(256, kMinWaves<F>) void k_heavy(const uint32_t* __restrict__ heavy_count,
                                                                const uint32_t* __restrict__ heavy_list,
                                                                const uint32_t* __restrict__ off, uint32_t nb,
-                                                               uint32_t lanes, const uint32_t* __restrict__ keys1,
+                                                               uint32_t lanes,
                                                                const typename MsmOps<F>::PtMem* __restrict__ pts1,
                                                                typename MsmOps<F>::PtMem* __restrict__ bucket_sum) {
   using O = MsmOps<F>;
@@ -534,10 +527,9 @@ __global__ __launch_bounds__(256, kMinWaves<F>) void k_heavy(const uint32_t* __r
   for (uint32_t h = blockIdx.x; h < n; h += gridDim.x) {
     const uint32_t b = heavy_list[h];
     const uint32_t s = off[b], e = off[b + 1];
-    const uint32_t lo = 2 * (s / K), hi = 2 * ((e - 1) / K) + 1;
+    const uint32_t pieces = (e - 1) / K - s / K + 1;
     typename O::Pt acc = O::inf();
-    for (uint32_t i = lo + lt; i < hi; i += nlt)
-      if (keys1[i] == b) O::add(acc, O::load(pts1 + i));
+    for (uint32_t p = lt; p < pieces; p += nlt) O::add(acc, O::load(pts1 + piece_slot(s, K, p)));
     block_sum<F>(acc, sh);
     if (lt == 0) O::store(bucket_sum + b, acc);
   }
@@ -759,7 +751,6 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
   // k_accumulate runs a fixed number of logical threads: one full round of the GPU at four waves per SIMD.
   constexpr bool is_g2 = sizeof(F) > sizeof(Fq);
   const uint32_t lanes = (uint32_t)ctx->cu_count * 4 * 64 * 4 / MsmOps<F>::LP;
-  const size_t o_keys1 = o;  o += align(2 * (size_t)lanes * 4);
   using PtMem = typename MsmOps<F>::PtMem;
   const size_t o_pts1 = o;   o += align(2 * (size_t)lanes * sizeof(PtMem));
   const size_t o_heavy = o;  o += align((size_t)sh.nb * 4);
@@ -784,7 +775,6 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
   uint32_t* err = (uint32_t*)(base + o_err);
   uint2* rec0 = (uint2*)(base + o_rec0);
   uint2* rec = (uint2*)(base + o_rec);
-  uint32_t* keys1 = (uint32_t*)(base + o_keys1);
   PtMem* pts1 = (PtMem*)(base + o_pts1);
   PtMem* bsum = (PtMem*)(base + o_bsum);
   PtMem* wsum = (PtMem*)(base + o_wsum);
@@ -828,14 +818,14 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
   {
     // work units (additions actually performed) are added by msm_collect from the entry count
     KernelTimer kt(ctx, is_g2 ? K_MSM_ACC0_G2 : K_MSM_ACC0_G1, 0.0, st);
-    k_accumulate<F><<<lanes * LP / 256, 256, 0, st>>>(jt, sh.nb, lanes, rec, off, keys1, pts1, bsum, err);
+    k_accumulate<F><<<lanes * LP / 256, 256, 0, st>>>(jt, sh.nb, lanes, rec, off, pts1, bsum, err);
   }
   {
     KernelTimer kt(ctx, is_g2 ? K_MSM_ACCN_G2 : K_MSM_ACCN_G1, (double)sh.nb, st);
-    constexpr int L = 2;
+    constexpr int L = 4;
     k_combine<F, L><<<(unsigned)(((size_t)sh.nb * L * LP + 255) / 256), 256, 0, st>>>(
-        sh.nb, lanes, off, keys1, pts1, bsum, err + 2, (uint32_t*)(base + o_heavy));
-    k_heavy<F><<<256, 256, 0, st>>>(err + 2, (const uint32_t*)(base + o_heavy), off, sh.nb, lanes, keys1, pts1, bsum);
+        sh.nb, lanes, off, pts1, bsum, err + 2, (uint32_t*)(base + o_heavy));
+    k_heavy<F><<<256, 256, 0, st>>>(err + 2, (const uint32_t*)(base + o_heavy), off, sh.nb, lanes, pts1, bsum);
   }
   {
     KernelTimer kt(ctx, is_g2 ? K_MSM_REDUCE_G2 : K_MSM_REDUCE_G1, (double)sh.nb, st);
