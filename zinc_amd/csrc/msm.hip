@@ -40,7 +40,7 @@ static constexpr uint32_t LIGHT_PIECES = 32;  // buckets cut into at most this m
 static constexpr int MAX_JOBS = 4;
 static constexpr uint32_t KEY_INVALID = 0xffffffffu;
 static constexpr uint32_t KEY_MASK = 0x00ffffffu;  // level-0 keys carry the window in the top byte
-static constexpr int RED_SEG = 8;     // buckets per lane in the window reduction
+static constexpr int RED_SEG = 2;     // buckets per lane in the window reduction
 
 // Minimum waves per SIMD requested from the register allocator for the curve kernels.
 template <class F>
