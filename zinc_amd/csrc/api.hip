@@ -188,14 +188,16 @@ zg16_status zg16_pk_upload(zg16_ctx* ctx, const zg16_pk_view* v, int shard_index
   shard_range(v->n_a, shard_index, shard_count, &pk->lo_a, &pk->hi_a);
   shard_range(v->n_b_g1, shard_index, shard_count, &pk->lo_b, &pk->hi_b);
   // Window tables 2^(c*w) * P for every query: the multiexps then share one bucket set across windows.
-  size_t largest = pk->hi_h - pk->lo_h;
-  for (size_t q : {pk->hi_l - pk->lo_l, pk->hi_a - pk->lo_a, pk->hi_b - pk->lo_b}) largest = q > largest ? q : largest;
-  pk->table_c = msm_table_window(largest);
-  ZG_TRY(upload_query<Fq>(ctx, &pk->h, v->h + 8 * pk->lo_h, pk->hi_h - pk->lo_h, pk->table_c));
+  size_t largest = pk->hi_l - pk->lo_l;
+  for (size_t q : {pk->hi_a - pk->lo_a, pk->hi_b - pk->lo_b}) largest = q > largest ? q : largest;
+  pk->table_c = msm_table_window(largest, 1);
+  pk->table_c_h = msm_table_window(pk->hi_h - pk->lo_h, 0);
+  pk->table_c_g2 = msm_table_window(pk->hi_b - pk->lo_b, 2);
+  ZG_TRY(upload_query<Fq>(ctx, &pk->h, v->h + 8 * pk->lo_h, pk->hi_h - pk->lo_h, pk->table_c_h));
   ZG_TRY(upload_query<Fq>(ctx, &pk->l, v->l + 8 * pk->lo_l, pk->hi_l - pk->lo_l, pk->table_c));
   ZG_TRY(upload_query<Fq>(ctx, &pk->a, v->a + 8 * pk->lo_a, pk->hi_a - pk->lo_a, pk->table_c));
   ZG_TRY(upload_query<Fq>(ctx, &pk->b1, v->b_g1 + 8 * pk->lo_b, pk->hi_b - pk->lo_b, pk->table_c));
-  ZG_TRY(upload_query<Fq2>(ctx, &pk->b2, v->b_g2 + 16 * pk->lo_b, pk->hi_b - pk->lo_b, pk->table_c));
+  ZG_TRY(upload_query<Fq2>(ctx, &pk->b2, v->b_g2 + 16 * pk->lo_b, pk->hi_b - pk->lo_b, pk->table_c_g2));
   memcpy(&pk->alpha_g1, v->alpha_g1, 64);
   memcpy(&pk->beta_g1, v->beta_g1, 64);
   memcpy(&pk->delta_g1, v->delta_g1, 64);
@@ -393,15 +395,21 @@ static zg16_status prove_partial_impl(zg16_ctx* ctx, const zg16_pk* pk, const zg
   const size_t hi_h = pk->hi_h < m - 1 ? pk->hi_h : m - 1;
   const size_t lo_h = pk->lo_h < hi_h ? pk->lo_h : hi_h;
   // the h table is laid out for the whole shard; skip the points below lo_h when the range was clipped
-  const MsmJob<Fq> job_h = {pk->h + (lo_h - pk->lo_h), h_coeffs + lo_h, nullptr, hi_h - lo_h, stride(pk->lo_h, pk->hi_h), tc, 0};
+  const MsmJob<Fq> job_h = {pk->h + (lo_h - pk->lo_h), h_coeffs + lo_h, nullptr, hi_h - lo_h, stride(pk->lo_h, pk->hi_h), pk->table_c_h, 0};
   const MsmJob<Fq> jobs_z[3] = {
       {pk->l, z + r->n_in + pk->lo_l, nullptr, pk->hi_l - pk->lo_l, stride(pk->lo_l, pk->hi_l), tc, 0},
       {pk->a, z, r->a_map + pk->lo_a, pk->hi_a - pk->lo_a, stride(pk->lo_a, pk->hi_a), tc, 1},
       {pk->b1, z, r->b_map + pk->lo_b, pk->hi_b - pk->lo_b, stride(pk->lo_b, pk->hi_b), tc, 2}};
+  // The main stream is the critical path (rows -> transforms -> h multiexp) and is enqueued first, so
+  // the GPU is not left waiting while the host queues the other pipelines' launches.
+  if (!h_external) ZG_TRY(spmv_device(ctx, r, z, a, b, c));
+  ZG_HIP(ctx, hipEventRecord(ev[E_SPMV], st));
+  if (!h_external) ZG_TRY(h_pipeline_device(ctx, a, b, c, r->log_m));
+  ZG_HIP(ctx, hipEventRecord(ev[E_NTT], st));
   {
     ZG_HIP(ctx, hipStreamWaitEvent(aux, ev[E_Z], 0));
     ZG_HIP(ctx, hipEventRecord(ev[E_G2_BEGIN], aux));
-    MsmJob<Fq2> jb = {pk->b2, z, r->b_map + pk->lo_b, pk->hi_b - pk->lo_b, stride(pk->lo_b, pk->hi_b), tc, 0};
+    MsmJob<Fq2> jb = {pk->b2, z, r->b_map + pk->lo_b, pk->hi_b - pk->lo_b, stride(pk->lo_b, pk->hi_b), pk->table_c_g2, 0};
     const MsmStreams ms = {aux, nullptr, nullptr, nullptr};
     ZG_TRY(msm_launch<Fq2>(ctx, ms, 2, pinned + MSM_PINNED_BYTES, &jb, 1, 1, &pend_g2));
     ZG_HIP(ctx, hipEventRecord(ev[E_G2_END], aux));
@@ -413,11 +421,6 @@ static zg16_status prove_partial_impl(zg16_ctx* ctx, const zg16_pk* pk, const zg
     ZG_TRY(msm_launch<Fq>(ctx, ms, 6, pinned + 2 * MSM_PINNED_BYTES, jobs_z, 3, 3, &pend_z));
     ZG_HIP(ctx, hipEventRecord(ev[E_Z_END], early));
   }
-
-  if (!h_external) ZG_TRY(spmv_device(ctx, r, z, a, b, c));
-  ZG_HIP(ctx, hipEventRecord(ev[E_SPMV], st));
-  if (!h_external) ZG_TRY(h_pipeline_device(ctx, a, b, c, r->log_m));
-  ZG_HIP(ctx, hipEventRecord(ev[E_NTT], st));
 
   G1XYZZ g1[3];
   if (tables) {
@@ -670,7 +673,7 @@ zg16_status zg16_bases_upload(zg16_ctx* ctx, int group, const uint64_t* bases, s
   b->ctx = ctx;
   b->group = group;
   b->n = n;
-  b->table_c = window_tables ? msm_table_window(n) : 0;
+  b->table_c = window_tables ? msm_table_window(n, 0) : 0;
   if (group == 1) {
     Affine<Fq>* p;
     ZG_TRY(upload_query<Fq>(ctx, &p, bases, n, b->table_c));

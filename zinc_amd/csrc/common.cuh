@@ -181,7 +181,7 @@ struct MsmJob {
 };
 // Window width / count used for key tables, and the kernel that fills windows 1..W-1 of a table whose
 // window 0 (n points, stride n) is already in place.
-uint32_t msm_table_window(size_t largest_query);
+uint32_t msm_table_window(size_t points, int role);  // role 0: h, 1: l / a / b_g1, 2: b_g2
 uint32_t msm_table_windows(uint32_t c);
 template <class F>
 zg16_status msm_build_table(zg16_ctx* ctx, Affine<F>* table, size_t n, uint32_t c);
@@ -194,7 +194,7 @@ zg16_status msm_g2_device(zg16_ctx* ctx, const MsmJob<Fq2>* jobs, int njobs, G2X
 // (MSM_PINNED_BYTES of page-locked host memory) and returns without waiting; once `ms.main` is idle
 // msm_collect turns the block into `ngroups` points.  Jobs of one launch may form several groups
 // (independent sums) only when every job brings a window table of the same width.
-static constexpr size_t MSM_PINNED_BYTES = 32768;
+static constexpr size_t MSM_PINNED_BYTES = 512 * 1024;
 struct MsmPending {
   void* pinned = nullptr;
   uint32_t nsets = 0, ngroups = 0, c = 0, shared = 0;

@@ -232,14 +232,16 @@ zg16_status zg16_pk_upload_bytes(zg16_ctx* ctx, const uint8_t* data, size_t len,
   range(pk->n_l, &pk->lo_l, &pk->hi_l);
   range(pk->n_a, &pk->lo_a, &pk->hi_a);
   range(pk->n_b1, &pk->lo_b, &pk->hi_b);
-  size_t largest = pk->hi_h - pk->lo_h;
-  for (size_t q : {pk->hi_l - pk->lo_l, pk->hi_a - pk->lo_a, pk->hi_b - pk->lo_b}) largest = q > largest ? q : largest;
-  pk->table_c = msm_table_window(largest);
-  ZG_TRY(decode_query<Fq>(ctx, vec[0], pk->lo_h, pk->hi_h, checked, pk->table_c, curve_b, names[0], &pk->h));
+  size_t largest = pk->hi_l - pk->lo_l;
+  for (size_t q : {pk->hi_a - pk->lo_a, pk->hi_b - pk->lo_b}) largest = q > largest ? q : largest;
+  pk->table_c = msm_table_window(largest, 1);
+  pk->table_c_h = msm_table_window(pk->hi_h - pk->lo_h, 0);
+  pk->table_c_g2 = msm_table_window(pk->hi_b - pk->lo_b, 2);
+  ZG_TRY(decode_query<Fq>(ctx, vec[0], pk->lo_h, pk->hi_h, checked, pk->table_c_h, curve_b, names[0], &pk->h));
   ZG_TRY(decode_query<Fq>(ctx, vec[1], pk->lo_l, pk->hi_l, checked, pk->table_c, curve_b, names[1], &pk->l));
   ZG_TRY(decode_query<Fq>(ctx, vec[2], pk->lo_a, pk->hi_a, checked, pk->table_c, curve_b, names[2], &pk->a));
   ZG_TRY(decode_query<Fq>(ctx, vec[3], pk->lo_b, pk->hi_b, checked, pk->table_c, curve_b, names[3], &pk->b1));
-  ZG_TRY(decode_query<Fq2>(ctx, vec[4], pk->lo_b, pk->hi_b, checked, pk->table_c, curve_b, names[4], &pk->b2));
+  ZG_TRY(decode_query<Fq2>(ctx, vec[4], pk->lo_b, pk->hi_b, checked, pk->table_c_g2, curve_b, names[4], &pk->b2));
   *out = pk.release();
   return ZG16_OK;
 }

@@ -27,8 +27,9 @@
 //                          each in k_heavy.
 //   5. k_sum_range       : plain tree sum for scalars equal to one (about half of a zinc witness);
 //                          they reach their bucket through a wave-aggregated counter, not a digit.
-//   6. k_bucket_reduce   : sum_b (b+1)*S_b by segment running sums + LDS tree
-//   7. host              : Horner over the W window sums (per-window layout only)
+//   6. k_split_sums x2   : each bucket set folded to a few dozen plain sums (no scalar multiplications)
+//   7. host              : sum_b (b+1)*S_b from the folded sums; Horner over the W window sums
+//                          (per-window layout only)
 #define ZG_OUTLINE_FIELD_MUL 1
 #include "common.cuh"
 #include "msm_ops.cuh"
@@ -40,7 +41,6 @@ static constexpr uint32_t LIGHT_PIECES = 32;  // buckets cut into at most this m
 static constexpr int MAX_JOBS = 4;
 static constexpr uint32_t KEY_INVALID = 0xffffffffu;
 static constexpr uint32_t KEY_MASK = 0x00ffffffu;  // level-0 keys carry the window in the top byte
-static constexpr int RED_SEG = 2;     // buckets per lane in the window reduction
 
 // Minimum waves per SIMD requested from the register allocator for the curve kernels.
 template <class F>
@@ -535,45 +535,68 @@ __global__ __launch_bounds__(256, kMinWaves<F>) void k_heavy(const uint32_t* __r
   }
 }
 
-// Bucket-set sums, stage 1: part[w][blk] = sum over this workgroup's buckets of (b+1) * S[w*B + b].
-// Grid (blocks per set, sets).  A logical thread folds RED_SEG consecutive buckets by running sums
-// and adds seg_start * (segment sum); the workgroup then tree-adds through LDS.
+// Weighted bucket sums without scalar multiplications.  sum_b (b+1)*S_b over B = R*H buckets with
+// b = hi*R + lo splits into  sum_lo lo*U_lo + sum_hi (R*hi + 1)*V_hi,  U_lo = sum_hi S_b (column
+// sums), V_hi = sum_lo S_b (row sums): two plain-sum arrays of R and H points.  Applying the same
+// split to U and V leaves four arrays of at most 2^ceil((c-1)/4) points whose small weighted sums
+// the host finishes (msm_collect) -- a CPU core adds points an order of magnitude faster than one
+// wave does, and the device part is two launches of log-depth sums.
+//
+// k_split_sums: each wave produces one output point.  Array a of set blockIdx.z holds count[a] =
+// r[a] * h[a] points at in + set*in_stride + in_off[a]; outputs are r[a] column sums (index mod r)
+// followed by h[a] row sums (index div r) at out_off[a].  With out_std the outputs are written in
+// the library-wide XYZZ form for the host instead.
+struct SplitShape {
+  uint32_t narr;
+  uint32_t in_off[2], r[2], h[2], out_off[2];
+  uint32_t in_stride, out_stride;
+};
+
 template <class F>
-__global__ __launch_bounds__(256, kMinWaves<F>) void k_bucket_reduce(const typename MsmOps<F>::PtMem* __restrict__ bucket_sum,
-                                                                       uint32_t B,
-                                                                       typename MsmOps<F>::PtMem* __restrict__ part) {
+__global__ __launch_bounds__(256, kMinWaves<F>) void k_split_sums(const typename MsmOps<F>::PtMem* __restrict__ in,
+                                                                    SplitShape ss,
+                                                                    typename MsmOps<F>::PtMem* __restrict__ out,
+                                                                    XYZZ<F>* __restrict__ out_std) {
   using O = MsmOps<F>;
-  __shared__ typename O::Pt sh[128];
-  const uint32_t w = blockIdx.y, lt = threadIdx.x / O::LP, nlt = 256 / O::LP;
-  const typename O::PtMem* S = bucket_sum + (size_t)w * B;
-  const uint32_t seg = (blockIdx.x * nlt + lt) * RED_SEG;
+  constexpr uint32_t LT = 64 / O::LP;  // logical threads per wave
+  const uint32_t a = blockIdx.y, set = blockIdx.z;
+  const uint32_t r = ss.r[a], h = ss.h[a];
+  const uint32_t task = blockIdx.x * 4 + threadIdx.x / 64;  // wave-uniform
+  if (task >= r + h) return;
+  const uint32_t lt = (threadIdx.x & 63) / O::LP;
+  const typename O::PtMem* X = in + (size_t)set * ss.in_stride + ss.in_off[a];
   typename O::Pt acc = O::inf();
-  if (seg < B) {
-    const uint32_t hi = seg + RED_SEG < B ? seg + RED_SEG : B;
-    typename O::Pt run = O::inf();
-    for (uint32_t b = hi; b-- > seg;) {
-      O::add(run, O::load(S + b));
-      O::add(acc, run);
-    }
-    // acc = sum (b - seg + 1) S_b ; add seg * run
-    if (seg) O::add(acc, mul_small<F>(run, seg));
+  if (task < r) {
+    for (uint32_t k = lt; k < h; k += LT) O::add(acc, O::load(X + (size_t)k * r + task));
+  } else {
+    const typename O::PtMem* row = X + (size_t)(task - r) * r;
+    for (uint32_t k = lt; k < r; k += LT) O::add(acc, O::load(row + k));
   }
-  block_sum<F>(acc, sh);
-  if (lt == 0) O::store(part + ((size_t)w * gridDim.x + blockIdx.x), acc);
+#pragma unroll 1
+  for (uint32_t d = LT / 2; d >= 1; d >>= 1) {
+    const typename O::Pt o = O::shfl_down(acc, d * O::LP);
+    if (lt < d) O::add(acc, o);
+  }
+  if (lt == 0) {
+    const size_t dst = (size_t)set * ss.out_stride + ss.out_off[a] + task;
+    if (out_std)
+      O::store_std(out_std + dst, acc);
+    else
+      O::store(out + dst, acc);
+  }
 }
 
-// out[w] = sum of part[w][0..count).  One workgroup per w.
+// out_std[w] = sum of part[w][0..count), in the library-wide XYZZ form.  One workgroup per w.
 template <class F>
 __global__ __launch_bounds__(256, kMinWaves<F>) void k_sum_partials(const typename MsmOps<F>::PtMem* __restrict__ part,
-                                                                      uint32_t count,
-                                                                      typename MsmOps<F>::PtMem* __restrict__ out) {
+                                                                      uint32_t count, XYZZ<F>* __restrict__ out_std) {
   using O = MsmOps<F>;
   __shared__ typename O::Pt sh[128];
   const uint32_t w = blockIdx.x, lt = threadIdx.x / O::LP, nlt = 256 / O::LP;
   typename O::Pt acc = O::inf();
   for (uint32_t i = lt; i < count; i += nlt) O::add(acc, O::load(part + ((size_t)w * count + i)));
   block_sum<F>(acc, sh);
-  if (lt == 0) O::store(out + w, acc);
+  if (lt == 0) O::store_std(out_std + w, acc);
 }
 
 // Plain sum of the bases whose scalar equals one, group blockIdx.y: the entries are
@@ -602,14 +625,6 @@ __global__ __launch_bounds__(256, kMinWaves<F>) void k_sum_range(JobTable<F> jt,
   }
   block_sum<F>(acc, sh);
   if (lt == 0) O::store(part + ((size_t)g * gridDim.x + blockIdx.x), acc);
-}
-
-// Results for the host: the library-wide XYZZ form.
-template <class F>
-__global__ void k_export(const typename MsmOps<F>::PtMem* __restrict__ in, uint32_t count, XYZZ<F>* __restrict__ out) {
-  using O = MsmOps<F>;
-  const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) / O::LP;
-  if (t < count) O::store_std(out + t, O::load(in + t));
 }
 
 // table[w*stride + i] = 2^(c*w) * table[i] for w in 1..W-1, every window in the internal packed form
@@ -642,19 +657,25 @@ static uint32_t pick_window(size_t n) {
   return (uint32_t)c;
 }
 
-// Table window for a key whose largest query has `largest_query` points: about 2^4..2^5 terms per
-// window per bucket keeps buckets inside k_combine's reach and the bucket reduction negligible.
+// Table window for a query of `points` points.  The h query meets dense scalars: about 2^4 terms
+// per window per bucket keeps buckets inside k_combine's reach and the bucket work small.  The
+// queries over the witness (role 1: l, a, b_g1 share one launch and one width; role 2: b_g2) meet
+// mostly bits, which bypass the buckets, so they get a narrower window.
 // Returns 0 when tables are switched off (ZG16_MSM_TABLE_WINDOW=0): per-window buckets are used.
-uint32_t msm_table_window(size_t largest_query) {
+// ZG16_MSM_TABLE_WINDOW sets every width, ZG16_MSM_TABLE_WINDOW_H / _W / _G2 one role's.
+uint32_t msm_table_window(size_t points, int role) {
+  static const char* const role_env[3] = {"ZG16_MSM_TABLE_WINDOW_H", "ZG16_MSM_TABLE_WINDOW_W", "ZG16_MSM_TABLE_WINDOW_G2"};
   const char* e = getenv("ZG16_MSM_TABLE_WINDOW");
+  if (e && atoi(e) == 0) return 0;
+  const char* er = getenv(role_env[role]);
+  if (er) e = er;
   if (e) {
     int v = atoi(e);
-    if (v == 0) return 0;
     if (v >= 8 && v <= 20) return (uint32_t)v;
   }
   unsigned lg = 0;
-  while (((size_t)2 << lg) <= largest_query) lg++;
-  int c = (int)lg - 4;
+  while (((size_t)2 << lg) <= points) lg++;
+  int c = (int)lg - (role == 0 ? 3 : 5);
   if (c < 8) c = 8;
   if (c > 20) c = 20;
   return (uint32_t)c;
@@ -674,7 +695,24 @@ zg16_status msm_build_table(zg16_ctx* ctx, Affine<F>* table, size_t n, uint32_t 
 template zg16_status msm_build_table<Fq>(zg16_ctx*, Affine<Fq>*, size_t, uint32_t);
 template zg16_status msm_build_table<Fq2>(zg16_ctx*, Affine<Fq2>*, size_t, uint32_t);
 
-// Result block in page-locked host memory: [0] identity-base flag, then (sets + groups) XYZZ points.
+// How a set of 2^bits buckets is folded on the device: R*H buckets -> U (R) and V (H), then
+// U -> r1 + h1 points and V -> r2 + h2 points, all sizes powers of two (logarithms held here).
+struct FoldShape {
+  uint32_t lR, lH, lr1, lh1, lr2, lh2;
+  explicit FoldShape(uint32_t bits) {
+    lR = (bits + 1) / 2;
+    lH = bits - lR;
+    lr1 = (lR + 1) / 2;
+    lh1 = lR - lr1;
+    lr2 = (lH + 1) / 2;
+    lh2 = lH - lr2;
+  }
+  uint32_t mid() const { return (1u << lR) + (1u << lH); }
+  uint32_t leaves() const { return (1u << lr1) + (1u << lh1) + (1u << lr2) + (1u << lh2); }
+};
+
+// Result block in page-locked host memory: [0] identity-base flag, [1] entry count, then
+// sets * leaves XYZZ points (the folded bucket sets) and one unit-scalar sum per group.
 static constexpr size_t PINNED_POINTS = 256;
 
 template <class F>
@@ -725,7 +763,9 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
   const size_t max_entries = (size_t)sh.W * n;
   if (max_entries >= 0xfffffff0ull) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "multiexp too large for 32-bit entry offsets");
   if (sh.nb + sh.G > KEY_MASK) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "too many multiexp buckets");
-  if ((nsets + sh.G) * sizeof(XYZZ<F>) + PINNED_POINTS > MSM_PINNED_BYTES)
+  const FoldShape fold(sh.c - 1);
+  const size_t nresult = (size_t)nsets * fold.leaves() + sh.G;
+  if (nresult * sizeof(XYZZ<F>) + PINNED_POINTS > MSM_PINNED_BYTES)
     return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "multiexp result block too large");
   const uint32_t ncount = sh.nb + sh.G;  // counters: digit buckets, then one unit-scalar bucket per group
 
@@ -755,15 +795,14 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
   const size_t o_pts1 = o;   o += align(2 * (size_t)lanes * sizeof(PtMem));
   const size_t o_heavy = o;  o += align((size_t)sh.nb * 4);
   const size_t o_bsum = o;   o += align((size_t)sh.nb * sizeof(PtMem));
-  const size_t o_wsum = o;   o += align((size_t)(nsets + sh.G) * sizeof(PtMem));
-  const size_t o_wstd = o;   o += align((size_t)(nsets + sh.G) * sizeof(XYZZ<F>));  // the same for the host
+  const size_t o_mid = o;    o += align((size_t)nsets * fold.mid() * sizeof(PtMem));
+  const size_t o_wstd = o;   o += align(nresult * sizeof(XYZZ<F>));  // the result block for the host
   const uint32_t ntiles = (ncount + SCAN_TILE - 1) / SCAN_TILE;
   constexpr uint32_t LP = MsmOps<F>::LP;
-  const uint32_t red_blocks = (sh.B + (256 / LP) * RED_SEG - 1) / ((256 / LP) * RED_SEG);
   uint32_t ones_blocks = (uint32_t)((n + 256 * 16 - 1) / (256 * 16));
   if (ones_blocks > 1024) ones_blocks = 1024;
   const size_t o_tiles = o;  o += align((size_t)(ntiles + 1) * 4);
-  const size_t o_part = o;   o += align((size_t)(nsets * red_blocks + sh.G * ones_blocks) * sizeof(PtMem));
+  const size_t o_part = o;   o += align((size_t)sh.G * ones_blocks * sizeof(PtMem));
   char* base;
   ZG_TRY(scratch_get(ctx, scratch_slot, o, (void**)&base));
   uint32_t* hist = (uint32_t*)(base + o_hist);
@@ -777,11 +816,10 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
   uint2* rec = (uint2*)(base + o_rec);
   PtMem* pts1 = (PtMem*)(base + o_pts1);
   PtMem* bsum = (PtMem*)(base + o_bsum);
-  PtMem* wsum = (PtMem*)(base + o_wsum);
+  PtMem* mid = (PtMem*)(base + o_mid);
   XYZZ<F>* wstd = (XYZZ<F>*)(base + o_wstd);
   uint32_t* tiles = (uint32_t*)(base + o_tiles);
-  PtMem* part = (PtMem*)(base + o_part);
-  PtMem* ones_part = part + (size_t)nsets * red_blocks;
+  PtMem* ones_part = (PtMem*)(base + o_part);
 
   ZG_HIP(ctx, hipMemsetAsync(base, 0, o_zero_end, st));  // every counter and flag
   ZG_HIP(ctx, hipMemsetAsync(bsum, 0, (size_t)sh.nb * sizeof(PtMem), st));
@@ -800,20 +838,20 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
   }
   // Everything below sizes its grid for the largest possible entry count and reads the actual
   // counts from `off` on the device, so the host never waits in the middle of a multiexp.
-  {
-    // The scalars equal to one: a plain tree sum per group, kept out of the segmented reduction.  It
-    // depends only on the sort, so it runs on the side stream beside the bucket pipeline when there is one.
-    hipStream_t so = ms.side ? ms.side : st;
-    if (ms.side) {
-      ZG_HIP(ctx, hipEventRecord(ms.ev_fork, st));
-      ZG_HIP(ctx, hipStreamWaitEvent(so, ms.ev_fork, 0));
-    }
-    {
-      KernelTimer kt(ctx, is_g2 ? K_MSM_ONES_G2 : K_MSM_ONES_G1, (double)n, so);
-      k_sum_range<F><<<dim3(ones_blocks, sh.G), 256, 0, so>>>(jt, rec, off, sh.nb, ones_part, err);
-      k_sum_partials<F><<<sh.G, 256, 0, so>>>(ones_part, ones_blocks, wsum + nsets);
-    }
-    if (ms.side) ZG_HIP(ctx, hipEventRecord(ms.ev_join, so));
+  // The scalars equal to one: a plain tree sum per group, kept out of the segmented reduction.  It
+  // depends only on the sort.  With a side stream it runs beside the bucket pipeline; without one it
+  // follows it, so that its two latency-bound launches do not hold back the accumulation.
+  auto unit_sums = [&](hipStream_t so) -> zg16_status {
+    KernelTimer kt(ctx, is_g2 ? K_MSM_ONES_G2 : K_MSM_ONES_G1, (double)n, so);
+    k_sum_range<F><<<dim3(ones_blocks, sh.G), 256, 0, so>>>(jt, rec, off, sh.nb, ones_part, err);
+    k_sum_partials<F><<<sh.G, 256, 0, so>>>(ones_part, ones_blocks, wstd + (size_t)nsets * fold.leaves());
+    return ZG16_OK;
+  };
+  if (ms.side) {
+    ZG_HIP(ctx, hipEventRecord(ms.ev_fork, st));
+    ZG_HIP(ctx, hipStreamWaitEvent(ms.side, ms.ev_fork, 0));
+    ZG_TRY(unit_sums(ms.side));
+    ZG_HIP(ctx, hipEventRecord(ms.ev_join, ms.side));
   }
   {
     // work units (additions actually performed) are added by msm_collect from the entry count
@@ -829,22 +867,75 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
   }
   {
     KernelTimer kt(ctx, is_g2 ? K_MSM_REDUCE_G2 : K_MSM_REDUCE_G1, (double)sh.nb, st);
-    k_bucket_reduce<F><<<dim3(red_blocks, nsets), 256, 0, st>>>(bsum, sh.B, part);
-    k_sum_partials<F><<<nsets, 256, 0, st>>>(part, red_blocks, wsum);
+    SplitShape s1 = {};
+    s1.narr = 1;
+    s1.r[0] = 1u << fold.lR;
+    s1.h[0] = 1u << fold.lH;
+    s1.in_stride = sh.B;
+    s1.out_stride = fold.mid();
+    k_split_sums<F><<<dim3((fold.mid() + 3) / 4, 1, nsets), 256, 0, st>>>(bsum, s1, mid, nullptr);
+    SplitShape s2 = {};
+    s2.narr = 2;
+    s2.r[0] = 1u << fold.lr1;
+    s2.h[0] = 1u << fold.lh1;
+    s2.in_off[1] = 1u << fold.lR;
+    s2.r[1] = 1u << fold.lr2;
+    s2.h[1] = 1u << fold.lh2;
+    s2.out_off[1] = s2.r[0] + s2.h[0];
+    s2.in_stride = fold.mid();
+    s2.out_stride = fold.leaves();
+    const uint32_t t2 = s2.r[0] + s2.h[0] > s2.r[1] + s2.h[1] ? s2.r[0] + s2.h[0] : s2.r[1] + s2.h[1];
+    k_split_sums<F><<<dim3((t2 + 3) / 4, 2, nsets), 256, 0, st>>>(mid, s2, nullptr, wstd);
   }
   ZG_HIP(ctx, hipGetLastError());
-  if (ms.side) ZG_HIP(ctx, hipStreamWaitEvent(st, ms.ev_join, 0));
+  if (ms.side)
+    ZG_HIP(ctx, hipStreamWaitEvent(st, ms.ev_join, 0));
+  else
+    ZG_TRY(unit_sums(st));
   ZG_HIP(ctx, hipMemcpyAsync(pinned, err, 4, hipMemcpyDeviceToHost, st));
   ZG_HIP(ctx, hipMemcpyAsync((char*)pinned + 4, off + sh.nb, 4, hipMemcpyDeviceToHost, st));
-  k_export<F><<<(nsets + sh.G) * LP / 256 + 1, 256, 0, st>>>(wsum, nsets + sh.G, wstd);
-  ZG_HIP(ctx, hipGetLastError());
-  ZG_HIP(ctx, hipMemcpyAsync((char*)pinned + PINNED_POINTS, wstd, (nsets + sh.G) * sizeof(XYZZ<F>),
-                             hipMemcpyDeviceToHost, st));
+  ZG_HIP(ctx, hipMemcpyAsync((char*)pinned + PINNED_POINTS, wstd, nresult * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
   pend->nsets = nsets;
   pend->acc_kernel = is_g2 ? K_MSM_ACC0_G2 : K_MSM_ACC0_G1;
   pend->c = sh.c;
   pend->shared = sh.shared;
   return ZG16_OK;
+}
+
+// sum_i i * x[i], and the plain sum when `plain` is given (host)
+template <class F>
+static XYZZ<F> index_weighted_sum(const XYZZ<F>* x, uint32_t n, XYZZ<F>* plain) {
+  XYZZ<F> run = XYZZ<F>::inf(), acc = XYZZ<F>::inf();
+  for (uint32_t i = n; i-- > 1;) {
+    add_full(run, x[i]);
+    add_full(acc, run);
+  }
+  if (plain) {
+    add_full(run, x[0]);
+    *plain = run;
+  }
+  return acc;
+}
+
+// The weighted sum of one bucket set from its folded form.  Bucket b = hi*R + lo with
+// lo = a1*r1 + b1, hi = a2*r2 + b2 has weight b + 1 = b1 + r1*a1 + R*(b2 + r2*a2) + 1; the four
+// arrays hold the sums of the buckets sharing b1, a1, b2, a2 in that order.
+template <class F>
+static XYZZ<F> fold_finish(const XYZZ<F>* leaf, const FoldShape& f) {
+  const XYZZ<F>* ua = leaf;
+  const XYZZ<F>* ub = ua + (1u << f.lr1);
+  const XYZZ<F>* va = ub + (1u << f.lh1);
+  const XYZZ<F>* vb = va + (1u << f.lr2);
+  XYZZ<F> all;
+  XYZZ<F> t = index_weighted_sum<F>(vb, 1u << f.lh2, nullptr);
+  for (uint32_t k = 0; k < f.lr2; k++) t = dbl(t);
+  add_full(t, index_weighted_sum<F>(va, 1u << f.lr2, &all));
+  for (uint32_t k = 0; k < f.lR - f.lr1; k++) t = dbl(t);
+  add_full(t, index_weighted_sum<F>(ub, 1u << f.lh1, nullptr));
+  for (uint32_t k = 0; k < f.lr1; k++) t = dbl(t);
+  add_full(t, index_weighted_sum<F>(ua, 1u << f.lr1, nullptr));
+  add_full(t, all);
+  return t;
 }
 
 template <class F>
@@ -855,19 +946,21 @@ zg16_status msm_collect(zg16_ctx* ctx, const MsmPending* pend, XYZZ<F>* out) {
   if (head[0]) return fail(ctx, ZG16_ERR_UNEXPECTED_IDENTITY, "multiexp consumed a base at infinity");
   if (ctx->profile) ctx->kstat[pend->acc_kernel].units += head[1];
   const XYZZ<F>* hw = (const XYZZ<F>*)((const char*)pend->pinned + PINNED_POINTS);
+  const FoldShape fold(pend->c - 1);
+  const XYZZ<F>* ones = hw + (size_t)pend->nsets * fold.leaves();
   if (pend->shared) {
     for (uint32_t g = 0; g < pend->ngroups; g++) {
-      out[g] = hw[g];
-      add_full(out[g], hw[pend->nsets + g]);  // the scalars equal to one
+      out[g] = fold_finish(hw + (size_t)g * fold.leaves(), fold);
+      add_full(out[g], ones[g]);  // the scalars equal to one
     }
     return ZG16_OK;
   }
   XYZZ<F> total = XYZZ<F>::inf();
   for (int w = (int)pend->nsets - 1; w >= 0; w--) {
     for (uint32_t k = 0; k < pend->c; k++) total = dbl(total);
-    add_full(total, hw[w]);
+    add_full(total, fold_finish(hw + (size_t)w * fold.leaves(), fold));
   }
-  add_full(total, hw[pend->nsets]);
+  add_full(total, ones[0]);
   out[0] = total;
   return ZG16_OK;
 }

@@ -46,6 +46,8 @@ struct NttDomain {
   Fr29* tw_b[2] = {};      // [dir][N]  pass B's (three-pass transforms only)
   Fr29* gm = nullptr;      // g^i / m
   Fr29* ginvm = nullptr;   // g^-i / m
+  Fr29* hz = nullptr;      // 32 * g^-i / (m * (g^m - 1)): the trailing factor of the fused H pipeline
+  Fr29* kz = nullptr;      // [1]  1 / (m * (g^m - 1))
   Fr29* w_small[2] = {};   // [dir][512]  w_1024^e
   Fr* g = nullptr;         // g^i (ABI form, for the stand-alone coset_fft pre-scaling)
   Fr minv, zinv;           // 1/m, 1/(g^m - 1)
@@ -70,15 +72,23 @@ __global__ __launch_bounds__(256) void k_to_fr29(const Fr* __restrict__ in, Fr29
   if (i < n) out[i] = from_r256<Fr29Params>(in[i]);
 }
 
+// LDS tile of nine-word elements.  Element i lives at slot(i) * 9: the odd word stride maps 64
+// distinct slots mod 64 to 64 distinct banks, and slot() folds index bits 6..9 into bits 0..5 so that
+// the lanes of a wave hit distinct slots mod 64 in every access pattern of the pass -- stride 4, 16
+// and 64 units of the radix-4 rounds, the bit-reversed load, the linear store -- instead of piling
+// up four to sixteen deep on the same banks.
+ZG_D uint32_t slot(uint32_t i) { return i ^ (((i >> 6) & 3) * 21) ^ ((i >> 8) & 3); }
 ZG_D Fr29 lds_get(const uint32_t* s, uint32_t i) {
   Fr29 r;
+  const uint32_t* e = s + slot(i) * 9;
 #pragma unroll
-  for (int k = 0; k < 9; k++) r.v[k] = s[i * 9 + k];
+  for (int k = 0; k < 9; k++) r.v[k] = e[k];
   return r;
 }
 ZG_D void lds_put(uint32_t* s, uint32_t i, const Fr29& x) {
+  uint32_t* e = s + slot(i) * 9;
 #pragma unroll
-  for (int k = 0; k < 9; k++) s[i * 9 + k] = x.v[k];
+  for (int k = 0; k < 9; k++) e[k] = x.v[k];
 }
 
 // One decimation-in-time butterfly on lazy values: (x0, x1) <- (x0 + t, x0 - t) with t = x1 * w, or
@@ -101,10 +111,18 @@ ZG_D void butterfly29(Fr29& x0, Fr29& x1, const Fr29& w, const uint32_t (&K)[9])
 // unpacked to nine 29-bit limbs on load, go through log2(R) decimation-in-time stages two at a time
 // (a lane holds the four elements of a radix-4 unit in registers, so LDS is touched every second
 // stage), and every output takes exactly one product -- the inter-pass twiddle, the trailing scale
-// factor, or one -- which also brings it back below 2p for the canonical packed store.
+// factor, another vector's element (mulvec) or one -- which also brings it back below 2p for the
+// canonical packed store.  subvec, when given, is subtracted element-wise from what is stored.
+struct PassExtras {
+  const Fr29* factor;  // per-element factor in store order, or a single constant (factor_const)
+  const Fr* mulvec;    // used when factor is null: out[o] = v * mulvec[o] * 2^-261 (mulvec may alias out)
+  const Fr* subvec;
+  uint32_t factor_const;
+};
+
 __global__ __launch_bounds__(256, 4) void k_ntt_pass(const Fr* __restrict__ in, Fr* __restrict__ out,
                                                      PassParams p, const Fr29* __restrict__ w_small,
-                                                     const Fr29* __restrict__ factor) {
+                                                     PassExtras ex) {
   __shared__ uint32_t s[TILE_ELEMS * 9];
   const uint32_t tid = threadIdx.x;
   const uint32_t logR = p.logR, logT = p.logT;
@@ -182,8 +200,16 @@ __global__ __launch_bounds__(256, 4) void k_ntt_pass(const Fr* __restrict__ in, 
     const Fr29 v = lds_get(s, (t << logR) + kk);
     const uint32_t o = out_base + kk * p.out_jstride + t * p.out_tstride;
     // the inter-pass twiddle or the trailing scale factor, laid out in store order (a streaming read)
-    const Fr29 f = factor ? factor[o] : Fr29::one();
-    out[o] = pack29<Fr29Params, FrParams>(mul(v, f));
+    Fr29 f;
+    if (ex.factor)
+      f = ex.factor[ex.factor_const ? 0 : o];
+    else if (ex.mulvec)
+      f = unpack29<Fr29Params>(ex.mulvec[o]);
+    else
+      f = Fr29::one();
+    Fr r = pack29<Fr29Params, FrParams>(mul(v, f));
+    if (ex.subvec) r = sub(r, ex.subvec[o]);
+    out[o] = r;
   }
 }
 
@@ -319,7 +345,7 @@ static zg16_status get_domain(zg16_ctx* ctx, unsigned log_n, NttDomain** out) {
   }
   const size_t N = (size_t)1 << log_n;
   const size_t n_tw = (d->plan.r1 ? 2 : 0) + (d->plan.r2 ? 2 : 0);
-  const size_t bytes29 = ((2 + n_tw) * N + 2 * 512) * sizeof(Fr29), bytes = bytes29 + N * sizeof(Fr);
+  const size_t bytes29 = ((3 + n_tw) * N + 2 * 512 + 8) * sizeof(Fr29), bytes = bytes29 + N * sizeof(Fr);
   // staging that is released again: the exponent-indexed power tables the store-order tables are built from
   const size_t stage_bytes = N * sizeof(Fr29) + (N + 512) * sizeof(Fr);
   void* stage = nullptr;
@@ -335,6 +361,8 @@ static zg16_status get_domain(zg16_ctx* ctx, unsigned log_n, NttDomain** out) {
   if (d->plan.r2) { d->tw_b[0] = p; p += N; d->tw_b[1] = p; p += N; }
   d->gm = p; p += N;
   d->ginvm = p; p += N;
+  d->hz = p; p += N;
+  d->kz = p; p += 8;
   d->w_small[0] = p; p += 512;
   d->w_small[1] = p; p += 512;
   d->g = (Fr*)((char*)d->block + bytes29);
@@ -367,6 +395,9 @@ static zg16_status get_domain(zg16_ctx* ctx, unsigned log_n, NttDomain** out) {
   }
   table29(d->gm, N, g, d->minv);
   table29(d->ginvm, N, g_inv, d->minv);
+  const Fr kz = mul(d->minv, d->zinv);
+  table29(d->hz, N, g_inv, mul(from_u64<FrParams>(32), kz));
+  table29(d->kz, 1, one, kz);
   table29(d->w_small[0], 512, w1024, one);
   table29(d->w_small[1], 512, w1024_inv, one);
   launch(d->g, N, g, one);
@@ -395,7 +426,7 @@ void ntt_free_domains(zg16_ctx* ctx) {
 // alias src.  The factor rides on the last pass's store, so `ifft` followed by a coset scaling (or
 // `icoset_fft`'s trailing g^-i / m) costs no extra product and no extra pass.
 static zg16_status ntt_raw(zg16_ctx* ctx, NttDomain* d, const Fr* src, Fr* dst, bool inverse,
-                           const Fr29* post_scale = nullptr) {
+                           const Fr29* post_scale = nullptr, const PassExtras* last = nullptr) {
   const unsigned n = d->log_n;
   if (n == 0) {
     if (dst != src) ZG_HIP(ctx, hipMemcpyAsync(dst, src, sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
@@ -410,15 +441,16 @@ static zg16_status ntt_raw(zg16_ctx* ctx, NttDomain* d, const Fr* src, Fr* dst, 
   const double bytes = 64.0 * (double)((size_t)1 << n);
   if (pl.r1) {
     KernelTimer kt(ctx, K_NTT_PASS, bytes);
-    k_ntt_pass<<<pl.grid_a, 256, 0, st>>>(src, tmp, pl.a, d->w_small[dir], d->tw_a[dir]);
+    k_ntt_pass<<<pl.grid_a, 256, 0, st>>>(src, tmp, pl.a, d->w_small[dir], PassExtras{d->tw_a[dir], nullptr, nullptr, 0});
   }
   if (pl.r2) {
     KernelTimer kt(ctx, K_NTT_PASS, bytes);
-    k_ntt_pass<<<pl.grid_b, 256, 0, st>>>(tmp, tmp, pl.b, d->w_small[dir], d->tw_b[dir]);
+    k_ntt_pass<<<pl.grid_b, 256, 0, st>>>(tmp, tmp, pl.b, d->w_small[dir], PassExtras{d->tw_b[dir], nullptr, nullptr, 0});
   }
   {
     KernelTimer kt(ctx, K_NTT_PASS, bytes);
-    k_ntt_pass<<<pl.grid_c, 256, 0, st>>>(pl.r1 ? tmp : src, dst, pl.c, d->w_small[dir], post_scale);
+    k_ntt_pass<<<pl.grid_c, 256, 0, st>>>(pl.r1 ? tmp : src, dst, pl.c, d->w_small[dir],
+                                          last ? *last : PassExtras{post_scale, nullptr, nullptr, 0});
   }
   ZG_HIP(ctx, hipGetLastError());
   return ZG16_OK;
@@ -472,9 +504,30 @@ zg16_status h_finish_device(zg16_ctx* ctx, Fr* a, const Fr* b, const Fr* c, unsi
   return ZG16_OK;
 }
 
+// The whole H computation in six transforms instead of upstream's seven.  icoset_fft is linear and
+// undoes coset_fft, so  icoset_fft((A*B - C) / Z) = icoset_fft(A*B / Z) - ifft(c) / Z  with A, B, C the
+// coset evaluations: c needs one inverse transform and no coset evaluation at all.  The element-wise
+// product rides on the last store of b's coset transform and the subtraction on the last store of
+// the final inverse transform, so there is no separate element-wise kernel either.  Field
+// arithmetic is exact: the coefficients equal upstream's.
 zg16_status h_pipeline_device(zg16_ctx* ctx, Fr* a, Fr* b, Fr* c, unsigned log_m) {
-  for (Fr* p : {a, b, c}) ZG_TRY(coset_evals_device(ctx, p, log_m));
-  return h_finish_device(ctx, a, b, c, log_m);
+  if (log_m == 0) {
+    for (Fr* p : {a, b, c}) ZG_TRY(coset_evals_device(ctx, p, log_m));
+    return h_finish_device(ctx, a, b, c, log_m);
+  }
+  NttDomain* d;
+  ZG_TRY(get_domain(ctx, log_m, &d));
+  ZG_TRY(coset_evals_device(ctx, a, log_m));
+  ZG_TRY(ntt_raw(ctx, d, b, b, true, d->gm));
+  // b <- A * B / 32 (a radix-2^256 value times another one, reduced by 2^261)
+  const PassExtras times_a = {nullptr, a, nullptr, 0};
+  ZG_TRY(ntt_raw(ctx, d, b, b, false, nullptr, &times_a));
+  // c <- ifft(c) / Z
+  const PassExtras scale_c = {d->kz, nullptr, nullptr, 1};
+  ZG_TRY(ntt_raw(ctx, d, c, c, true, nullptr, &scale_c));
+  // a <- icoset_fft(A * B) / Z - c
+  const PassExtras finish = {d->hz, nullptr, c, 0};
+  return ntt_raw(ctx, d, b, a, true, nullptr, &finish);
 }
 
 }  // namespace zg

@@ -43,9 +43,11 @@ struct zg16_pk {
   size_t lo_h = 0, hi_h = 0, lo_l = 0, hi_l = 0, lo_a = 0, hi_a = 0, lo_b = 0, hi_b = 0;
   zg::G1Affine *h = nullptr, *l = nullptr, *a = nullptr, *b1 = nullptr;
   zg::G2Affine* b2 = nullptr;
-  // When table_c != 0 each query array holds msm_table_windows(table_c) windows of its shard:
-  // q[w * (hi - lo) + k] = 2^(table_c * w) * P_(lo + k).
-  uint32_t table_c = 0;
+  // When table_c != 0 each query array holds msm_table_windows(c) windows of its shard, c being the
+  // query's own width below: q[w * (hi - lo) + k] = 2^(c * w) * P_(lo + k).
+  uint32_t table_c = 0;       // l, a, b_g1 (one launch, one width)
+  uint32_t table_c_h = 0;     // h
+  uint32_t table_c_g2 = 0;    // b_g2
   zg::G1Affine alpha_g1, beta_g1, delta_g1;
   zg::G2Affine beta_g2, delta_g2;
 };
