@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--dense", action="store_true", help="all aux values uniform (multiexp worst case)")
     ap.add_argument("--cpu-log-rows", type=int, default=20, help="circuit size of the CPU-baseline sample (2^20: seconds of CPU work on all host cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timers", action="store_true",
+                    help="leave the per-kernel HIP-event timers off (no roofline in the output): shows what they cost")
     ap.add_argument("--split-transforms", choices=("auto", "on", "off"), default="auto",
                     help="run the A/B/C transform chains on different ranks (auto: 3+ ranks and 2^22+ rows)")
     return ap.parse_args()
@@ -134,7 +136,9 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    ctx.profile(True, reset=True)
+    # timed steps carry HIP-event timers on the dominant kernels only; the full per-kernel table comes
+    # from extra untimed steps below (timing every launch costs about 3 % of a step)
+    ctx.profile(0 if args.no_kernel_timers else 2, reset=True)
     fence()
     t_start = time.perf_counter()
     for _ in range(args.steps):
@@ -143,6 +147,24 @@ def main():
     elapsed = time.perf_counter() - t_start
     stats = ctx.kernel_stats()
     stage = ctx.timings()
+    table_steps = 0 if args.no_kernel_timers else 3
+    ctx.profile(bool(table_steps), reset=True)
+    for _ in range(table_steps):
+        step()
+    fence()
+    stats_all = ctx.kernel_stats()
+    # the same with every stage on one stream: per-kernel durations free of the contention between the
+    # overlapped pipelines (the step itself is slower that way)
+    stats_serial = {}
+    if table_steps and world == 1:
+        ctx.serial(True)
+        step()
+        ctx.profile(True, reset=True)
+        for _ in range(table_steps):
+            step()
+        fence()
+        stats_serial = ctx.kernel_stats()
+        ctx.serial(False)
     ctx.profile(False, reset=False)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -151,10 +173,11 @@ def main():
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
-        # dominant kernel by accumulated device time on this rank
-        dom = max(stats.items(), key=lambda kv: kv[1][0])
-        per_kernel = {k: {"ms_per_step": v[0] / args.steps, "launches_per_step": v[1] / args.steps}
-                      for k, v in stats.items() if v[1]}
+        # dominant kernel: the largest uncontended device time per step (the overlapped timings count shared
+        # time once per kernel that was resident)
+        dom = max((stats_serial or stats).items(), key=lambda kv: kv[1][0])
+        per_kernel = {k: {"ms_per_step": v[0] / table_steps, "launches_per_step": v[1] / table_steps}
+                      for k, v in stats_all.items() if v[1]}
 
         pmc = {}
         pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_2p%d.json" % args.log_rows)
@@ -169,7 +192,7 @@ def main():
                 return None
             return (k["fetch_bytes_per_launch"] if streaming else k["fetch_bytes_per_launch_raw"]) + k["write_bytes_per_launch"]
 
-        def valu_roofline(name, fq_mul_per_add, pmc_name):
+        def valu_roofline(name, fq_mul_per_add, pmc_name, stats=stats):
             ms, launches, adds = stats[name]
             if not launches:
                 return None
@@ -179,7 +202,7 @@ def main():
                     "avg_launch_ms": ms / launches, "adds_per_launch": adds / launches,
                     "frac_of_measured_mad_rate": ach / VALU_MAD_MEASURED}
 
-        def hbm_roofline(name, pmc_name, fr_mul_per_byte=None):
+        def hbm_roofline(name, pmc_name, fr_mul_per_byte=None, stats=stats):
             ms, launches, nbytes = stats[name]
             if not launches:
                 return None
@@ -194,14 +217,24 @@ def main():
                 r["valu_frac"] = mads / VALU_MAD_PEAK
             return r
 
-        # k_ntt_pass: a radix-2^10 pass spends 5 butterfly products + 1 twiddle product per element = 6 per 64 bytes
-        rooflines = {
-            "k_accumulate<G1>": valu_roofline("k_accumulate<G1>", FQ_MUL_PER_G1_MADD, "k_accumulate<Fq >"),
-            "k_accumulate<G2>": valu_roofline("k_accumulate<G2>", FQ_MUL_PER_G2_MADD, "k_accumulate<Fq2>"),
-            "k_ntt_pass": hbm_roofline("k_ntt_pass", "k_ntt_pass", 6.0 / 64.0),
-            "k_spmv_short+long": hbm_roofline("k_spmv_short+long", "k_spmv_short"),
-        }
+        # k_ntt_pass: a radix-2^10 pass spends 4.25 butterfly products (ten stages, half a product per element each,
+        # less the trivial twiddles of the first two) + 1 factor product per element = 5.25 per 64 bytes
+        def all_rooflines(st):
+            return {
+                "k_accumulate<G1>": valu_roofline("k_accumulate<G1>", FQ_MUL_PER_G1_MADD, "k_accumulate<Fq >", st),
+                "k_accumulate<G2>": valu_roofline("k_accumulate<G2>", FQ_MUL_PER_G2_MADD, "k_accumulate<Fq2>", st),
+                "k_ntt_pass": hbm_roofline("k_ntt_pass", "k_ntt_pass", 5.25 / 64.0, st),
+                "k_spmv_short+long": hbm_roofline("k_spmv_short+long", "k_spmv_short", None, st),
+            }
+
+        rooflines = all_rooflines(stats)   # live: HIP events over the timed steps (pipelines overlapped)
         roofline = rooflines.get(dom[0]) or rooflines["k_accumulate<G1>"]
+        if stats_serial:
+            un = all_rooflines(stats_serial)
+            for k, v in rooflines.items():
+                if v and un.get(k):
+                    v["uncontended"] = {f: un[k][f] for f in ("achieved", "frac", "avg_launch_ms", "frac_of_measured_mad_rate",
+                                                              "valu_achieved_Tmad_s", "valu_frac") if f in un[k]}
         out = {
             "metric": "groth16_prove_latency_2^%d_constraints" % args.log_rows,
             "value": ms_per_step / 1e3,
@@ -222,6 +255,9 @@ def main():
             "constraints_per_s": n_rows / (ms_per_step / 1e3),
             "stage_ms_last_step": stage,
             "kernels": per_kernel,
+            "kernels_from": "%d extra untimed steps with every launch timed" % table_steps,
+            "kernels_uncontended": {k: {"ms_per_step": v[0] / table_steps, "launches_per_step": v[1] / table_steps}
+                                    for k, v in stats_serial.items() if v[1]},
             "roofline": roofline,
             "roofline_other": {k: v for k, v in rooflines.items() if v and v is not roofline},
             "setup_s_untimed": setup_s,

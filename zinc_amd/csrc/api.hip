@@ -359,12 +359,21 @@ static zg16_status prove_partial_impl(zg16_ctx* ctx, const zg16_pk* pk, const zg
   ZG_HIP(ctx, hipSetDevice(ctx->device));
   zg16_timings& tm = ctx->timings;
   tm = zg16_timings();
+  // ZG16_HOST_TRACE=1: host-side timestamps (us since entry) of the enqueue and wait points, on stderr
+  static const bool host_trace = getenv("ZG16_HOST_TRACE") && atoi(getenv("ZG16_HOST_TRACE")) != 0;
+  const auto t_entry = std::chrono::steady_clock::now();
+  auto mark = [&](const char* what) {
+    if (host_trace)
+      fprintf(stderr, "[zg16 host] %8.1f us  %s\n",
+              std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_entry).count(), what);
+  };
   // Stage boundaries are events; nothing below waits on the host until every kernel is enqueued.
   enum { E_BEGIN, E_Z, E_SPMV, E_NTT, E_G1, E_G2_BEGIN, E_G2_END, E_END, E_Z_END = 14 };
   hipEvent_t* ev = ctx->ev;
   // ZG16_SERIAL=1 puts every stage on the main stream: slower, but per-kernel timings are then free of
   // contention between the pipelines (used for the uncontended roofline figures)
-  static const bool serial = getenv("ZG16_SERIAL") && atoi(getenv("ZG16_SERIAL")) != 0;
+  static const bool serial_env = getenv("ZG16_SERIAL") && atoi(getenv("ZG16_SERIAL")) != 0;
+  const bool serial = ctx->serial >= 0 ? ctx->serial != 0 : serial_env;
   hipStream_t st = ctx->stream, aux = serial ? st : ctx->aux_stream;
   const size_t m = (size_t)1 << r->log_m;
   const uint32_t tc = pk->table_c;
@@ -406,6 +415,7 @@ static zg16_status prove_partial_impl(zg16_ctx* ctx, const zg16_pk* pk, const zg
   ZG_HIP(ctx, hipEventRecord(ev[E_SPMV], st));
   if (!h_external) ZG_TRY(h_pipeline_device(ctx, a, b, c, r->log_m));
   ZG_HIP(ctx, hipEventRecord(ev[E_NTT], st));
+  mark("rows and transforms enqueued");
   {
     ZG_HIP(ctx, hipStreamWaitEvent(aux, ev[E_Z], 0));
     ZG_HIP(ctx, hipEventRecord(ev[E_G2_BEGIN], aux));
@@ -438,6 +448,7 @@ static zg16_status prove_partial_impl(zg16_ctx* ctx, const zg16_pk* pk, const zg
   }
   ZG_HIP(ctx, hipStreamWaitEvent(st, ev[E_G2_END], 0));
   ZG_HIP(ctx, hipEventRecord(ev[E_END], st));
+  mark("everything enqueued");
   G2XYZZ qb2;
   bool early_done = false;
   if (tables && early) {
@@ -445,12 +456,20 @@ static zg16_status prove_partial_impl(zg16_ctx* ctx, const zg16_pk* pk, const zg
     ZG_HIP(ctx, hipEventSynchronize(ev[E_Z_END]));
     ZG_TRY(msm_collect<Fq>(ctx, &pend_z, g1));
     early->with_g1(g1[1], g1[2]);
+    mark("witness-query multiexps collected");
     ZG_HIP(ctx, hipEventSynchronize(ev[E_G2_END]));
     ZG_TRY(msm_collect<Fq2>(ctx, &pend_g2, &qb2));
     early->with_g2(qb2);
     early_done = true;
+    mark("G2 multiexp collected");
   }
-  ZG_HIP(ctx, hipEventSynchronize(ev[E_END]));
+  {
+    // the proof waits on this one: poll instead of sleeping in the runtime's wait
+    hipError_t q;
+    while ((q = hipEventQuery(ev[E_END])) == hipErrorNotReady) __builtin_ia32_pause();
+    ZG_HIP(ctx, q);
+  }
+  mark("GPU idle");
   if (tables) {
     G1XYZZ h_sum;
     if (!early_done) ZG_TRY(msm_collect<Fq>(ctx, &pend_z, g1));
@@ -465,6 +484,7 @@ static zg16_status prove_partial_impl(zg16_ctx* ctx, const zg16_pk* pk, const zg
   memcpy(out->a, &g1[1], sizeof g1[1]);
   memcpy(out->b1, &g1[2], sizeof g1[2]);
   memcpy(out->b2, &qb2, sizeof qb2);
+  mark("h multiexp collected");
   ZG_HIP(ctx, hipEventElapsedTime(&tm.upload_ms, ev[E_BEGIN], ev[E_Z]));
   ZG_HIP(ctx, hipEventElapsedTime(&tm.spmv_ms, ev[E_Z], ev[E_SPMV]));
   ZG_HIP(ctx, hipEventElapsedTime(&tm.ntt_ms, ev[E_SPMV], ev[E_NTT]));
@@ -472,6 +492,7 @@ static zg16_status prove_partial_impl(zg16_ctx* ctx, const zg16_pk* pk, const zg
   ZG_HIP(ctx, hipEventElapsedTime(&tm.msm_g2_ms, ev[E_G2_BEGIN], ev[E_G2_END]));  // overlaps the stages above
   ZG_HIP(ctx, hipEventElapsedTime(&tm.total_ms, ev[E_BEGIN], ev[E_END]));
   profile_collect(ctx);
+  mark("timings read");
   return ZG16_OK;
 }
 
@@ -577,11 +598,17 @@ zg16_status zg16_prove(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1cs* r, con
 static const char* const kKernelNames[K_COUNT] = {
     "k_spmv_short+long", "k_ntt_pass", "k_scale_powers", "k_mul_sub_scale", "k_sort_*+k_fine_*+k_scan_*", "k_scan",
     "k_accumulate<G1>", "k_accumulate<G2>", "k_combine+k_heavy<G1>", "k_combine+k_heavy<G2>",
-    "k_bucket_reduce<G1>", "k_bucket_reduce<G2>", "k_sum_range<G1>", "k_sum_range<G2>"};
+    "k_split_sums<G1>", "k_split_sums<G2>", "k_sum_range<G1>", "k_sum_range<G2>"};
 
 zg16_status zg16_profile_enable(zg16_ctx* ctx, int on) {
   if (!ctx) return ZG16_ERR_INVALID_ARGUMENT;
-  ctx->profile = on != 0;
+  ctx->profile = on == 2 ? 2 : (on != 0);
+  return ZG16_OK;
+}
+
+zg16_status zg16_profile_serial(zg16_ctx* ctx, int on) {
+  if (!ctx) return ZG16_ERR_INVALID_ARGUMENT;
+  ctx->serial = on < 0 ? -1 : (on != 0);
   return ZG16_OK;
 }
 

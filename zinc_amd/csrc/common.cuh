@@ -36,7 +36,8 @@ struct PendingTiming {
 
 struct zg16_ctx {
   int device = 0;
-  bool profile = false;
+  int serial = -1;  // 1: every stage of a prove on the main stream, 0: overlapped pipelines, -1: as ZG16_SERIAL says
+  int profile = 0;  // 0: off, 1: every kernel kind, 2: only the kinds a roofline is reported for
   zg::KernelStat kstat[zg::K_COUNT];
   std::vector<zg::PendingTiming> pending;
   std::vector<hipEvent_t> event_pool;
@@ -107,7 +108,7 @@ struct KernelTimer {
   bool on;
   hipStream_t st;
   KernelTimer(zg16_ctx* c, int id, double units, hipStream_t stream = nullptr)
-      : ctx(c), on(c->profile), st(stream ? stream : c->stream) {
+      : ctx(c), on(c->profile == 1 || (c->profile == 2 && roofline_kind(id))), st(stream ? stream : c->stream) {
     if (!on) return;
     p.id = id;
     p.units = units;
@@ -120,6 +121,9 @@ struct KernelTimer {
     if (!on) return;
     (void)hipEventRecord(p.b, st);
     ctx->pending.push_back(p);
+  }
+  static bool roofline_kind(int id) {
+    return id == K_SPMV || id == K_NTT_PASS || id == K_MSM_ACC0_G1 || id == K_MSM_ACC0_G2;
   }
   hipEvent_t grab() {
     if (!ctx->event_pool.empty()) {

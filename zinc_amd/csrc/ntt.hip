@@ -517,14 +517,14 @@ zg16_status h_pipeline_device(zg16_ctx* ctx, Fr* a, Fr* b, Fr* c, unsigned log_m
   }
   NttDomain* d;
   ZG_TRY(get_domain(ctx, log_m, &d));
+  // c <- ifft(c) / Z
+  const PassExtras scale_c = {d->kz, nullptr, nullptr, 1};
+  ZG_TRY(ntt_raw(ctx, d, c, c, true, nullptr, &scale_c));
   ZG_TRY(coset_evals_device(ctx, a, log_m));
   ZG_TRY(ntt_raw(ctx, d, b, b, true, d->gm));
   // b <- A * B / 32 (a radix-2^256 value times another one, reduced by 2^261)
   const PassExtras times_a = {nullptr, a, nullptr, 0};
   ZG_TRY(ntt_raw(ctx, d, b, b, false, nullptr, &times_a));
-  // c <- ifft(c) / Z
-  const PassExtras scale_c = {d->kz, nullptr, nullptr, 1};
-  ZG_TRY(ntt_raw(ctx, d, c, c, true, nullptr, &scale_c));
   // a <- icoset_fft(A * B) / Z - c
   const PassExtras finish = {d->hz, nullptr, c, 0};
   return ntt_raw(ctx, d, b, a, true, nullptr, &finish);

@@ -60,9 +60,14 @@ class Context:
         return {n: getattr(t, n) for n, _ in t._fields_}
 
     def profile(self, on=True, reset=True):
+        """on: False / True (every kernel kind) / 2 (only the kinds a roofline is reported for)."""
         _check(self.handle, self._lib.zg16_profile_enable(self.handle, int(on)))
         if reset:
             _check(self.handle, self._lib.zg16_profile_reset(self.handle))
+
+    def serial(self, on):
+        """True: proves issue every stage on one stream (uncontended per-kernel timings); False: overlapped."""
+        _check(self.handle, self._lib.zg16_profile_serial(self.handle, int(on)))
 
     def kernel_stats(self):
         """{kernel name: (total_ms, launches, units)} since the last reset."""

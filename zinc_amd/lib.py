@@ -98,6 +98,7 @@ SYMBOLS = [
     ("zg16_selftest_field", C.c_int, [C.c_void_p, C.c_int, C.c_int, u64p, u64p, C.c_size_t, u64p]),
     ("zg16_selftest_group", C.c_int, [C.c_void_p, C.c_int, C.c_int, u64p, u64p, C.c_size_t, u64p]),
     ("zg16_profile_enable", C.c_int, [C.c_void_p, C.c_int]),
+    ("zg16_profile_serial", C.c_int, [C.c_void_p, C.c_int]),
     ("zg16_profile_reset", C.c_int, [C.c_void_p]),
     ("zg16_profile_kernel_count", C.c_int, []),
     ("zg16_profile_get", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double),
