@@ -138,6 +138,17 @@ zg16_status zg16_prove(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1cs* r1cs,
                        const uint64_t* z_in, const uint64_t* z_aux, int witness_on_device,
                        const uint64_t r[4], const uint64_t s[4], zg16_proof* out);
 
+/* The same for a host that keeps bellman's own row evaluation (`ProvingAssignment::enforce` pushes
+ * a.evaluate(), b.evaluate(), c.evaluate() per constraint, including the n_inputs extra rows that
+ * `create_proof` appends): a, b, c hold r1cs.n_rows Fr each, in host memory or, with
+ * `evals_on_device`, device memory.  The matrices in `r1cs` are then used only for their shape and
+ * density maps; the row-evaluation kernels do not run. */
+zg16_status zg16_prove_from_evals(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1cs* r1cs,
+                                  const uint64_t* a, const uint64_t* b, const uint64_t* c,
+                                  int evals_on_device, const uint64_t* z_in, const uint64_t* z_aux,
+                                  int witness_on_device, const uint64_t r[4], const uint64_t s[4],
+                                  zg16_proof* out);
+
 /* bellman `Proof::write`: the 128 bytes whose hex `zvm prove` prints
  * (zinc-vm/src/zvm/arguments/command/prove.rs:171-174).  Host arithmetic only. */
 zg16_status zg16_proof_encode(const zg16_proof* proof, uint8_t out[128]);

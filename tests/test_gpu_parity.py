@@ -359,6 +359,10 @@ def test_prove_vs_cpu_oracle(gpu_ctx, log_rows, dense):
     got = prove_recorded(gpu_ctx, key, mat, zi, za, rs[0], rs[1])
     for g, w in zip((got.raw.a, got.raw.b, got.raw.c), want):
         assert np.array_equal(np.frombuffer(bytes(g), dtype=np.uint64), w)
+    # a host that keeps bellman's row evaluation hands a, b, c over instead: same proof
+    from zinc_amd.groth16 import prove_from_evals
+    ev = prove_from_evals(gpu_ctx, key, mat, ea, eb, ec, zi, za, rs[0], rs[1])
+    assert bytes(ev.raw) == bytes(got.raw)
     # the two-shard path gives the same proof (what two GPUs would compute, run back to back here)
     from zinc_amd.distributed import finish
     parts = (zlib.Partial * 2)()

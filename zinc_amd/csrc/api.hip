@@ -350,9 +350,15 @@ struct Assembly {
 // elsewhere, or null to evaluate the rows and run the transforms here.
 // early: when given (single-GPU proof), its witness-side step runs on the host as soon as the a, b_g1
 // and b_g2 sums are back, beside the h multiexp.
+// evals: when given, the n_rows row evaluations of A, B and C computed by the caller (host memory, or
+// device memory with evals_on_device); the row evaluation here is skipped.
+struct RowEvals {
+  const uint64_t* v[3];
+  int on_device;
+};
 static zg16_status prove_partial_impl(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1cs* r, const uint64_t* z_in,
                                       const uint64_t* z_aux, int on_device, const Fr* h_external, zg16_partial* out,
-                                      Assembly* early = nullptr) {
+                                      Assembly* early = nullptr, const RowEvals* evals = nullptr) {
   if (!ctx || !pk || !r || !out) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "bad arguments to zg16_prove_partial");
   if (pk->ctx != ctx || r->ctx != ctx) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "handles belong to another context");
   ZG_TRY(check_key_fits(ctx, pk, r));
@@ -411,7 +417,16 @@ static zg16_status prove_partial_impl(zg16_ctx* ctx, const zg16_pk* pk, const zg
       {pk->b1, z, r->b_map + pk->lo_b, pk->hi_b - pk->lo_b, stride(pk->lo_b, pk->hi_b), tc, 2}};
   // The main stream is the critical path (rows -> transforms -> h multiexp) and is enqueued first, so
   // the GPU is not left waiting while the host queues the other pipelines' launches.
-  if (!h_external) ZG_TRY(spmv_device(ctx, r, z, a, b, c));
+  if (!h_external) {
+    if (evals) {
+      Fr* dst[3] = {a, b, c};
+      for (int k = 0; k < 3; k++)
+        ZG_HIP(ctx, hipMemcpyAsync(dst[k], evals->v[k], r->n_rows * sizeof(Fr),
+                                   evals->on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    } else {
+      ZG_TRY(spmv_device(ctx, r, z, a, b, c));
+    }
+  }
   ZG_HIP(ctx, hipEventRecord(ev[E_SPMV], st));
   if (!h_external) ZG_TRY(h_pipeline_device(ctx, a, b, c, r->log_m));
   ZG_HIP(ctx, hipEventRecord(ev[E_NTT], st));
@@ -572,8 +587,9 @@ zg16_status zg16_prove_finish(const zg16_pk_view* v, const zg16_partial* parts, 
   return ZG16_OK;
 }
 
-zg16_status zg16_prove(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1cs* r, const uint64_t* z_in, const uint64_t* z_aux,
-                       int on_device, const uint64_t r_[4], const uint64_t s_[4], zg16_proof* out) {
+static zg16_status prove_full(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1cs* r, const uint64_t* z_in,
+                              const uint64_t* z_aux, int on_device, const uint64_t r_[4], const uint64_t s_[4],
+                              zg16_proof* out, const RowEvals* evals) {
   if (!ctx || !pk) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "bad arguments to zg16_prove");
   if (pk->shard_count != 1) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "zg16_prove needs an unsharded key");
   if (pk->delta_g1.is_inf() || pk->delta_g2.is_inf())
@@ -585,7 +601,7 @@ zg16_status zg16_prove(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1cs* r, con
   as.rc = from_mont(load_fr(r_));
   as.sc = from_mont(load_fr(s_));
   zg16_partial part;
-  ZG_TRY(prove_partial_impl(ctx, pk, r, z_in, z_aux, on_device, nullptr, &part, &as));
+  ZG_TRY(prove_partial_impl(ctx, pk, r, z_in, z_aux, on_device, nullptr, &part, &as, evals));
   auto t0 = std::chrono::steady_clock::now();
   G1XYZZ hl;
   memcpy(&hl, part.hl, sizeof hl);
@@ -593,6 +609,19 @@ zg16_status zg16_prove(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1cs* r, con
   ctx->timings.finish_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   ctx->timings.total_ms += ctx->timings.finish_ms;
   return ZG16_OK;
+}
+
+zg16_status zg16_prove(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1cs* r, const uint64_t* z_in, const uint64_t* z_aux,
+                       int on_device, const uint64_t r_[4], const uint64_t s_[4], zg16_proof* out) {
+  return prove_full(ctx, pk, r, z_in, z_aux, on_device, r_, s_, out, nullptr);
+}
+
+zg16_status zg16_prove_from_evals(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1cs* r, const uint64_t* a, const uint64_t* b,
+                                  const uint64_t* c, int evals_on_device, const uint64_t* z_in, const uint64_t* z_aux,
+                                  int on_device, const uint64_t r_[4], const uint64_t s_[4], zg16_proof* out) {
+  if (!a || !b || !c) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "zg16_prove_from_evals needs the three row-evaluation vectors");
+  const RowEvals ev = {{a, b, c}, evals_on_device};
+  return prove_full(ctx, pk, r, z_in, z_aux, on_device, r_, s_, out, &ev);
 }
 
 static const char* const kKernelNames[K_COUNT] = {

@@ -369,6 +369,22 @@ def prove_recorded(ctx, dev_key, dev_r1cs, z_in, z_aux, r_mont, s_mont):
     return Proof(raw)
 
 
+def prove_from_evals(ctx, dev_key, dev_r1cs, a, b, c, z_in, z_aux, r_mont, s_mont):
+    """zg16_prove_from_evals: like prove_recorded, with the row evaluations a, b, c ((n_rows, 4) uint64
+    Montgomery Fr each, as bellman's ProvingAssignment collects them) supplied by the caller."""
+    raw = _lib.Proof()
+    ev = [np.ascontiguousarray(x, dtype=np.uint64).reshape(-1, 4) for x in (a, b, c)]
+    zi = np.ascontiguousarray(z_in, dtype=np.uint64).reshape(-1, 4)
+    za = np.ascontiguousarray(z_aux, dtype=np.uint64).reshape(-1, 4)
+    r_mont = np.ascontiguousarray(r_mont, dtype=np.uint64).reshape(4)
+    s_mont = np.ascontiguousarray(s_mont, dtype=np.uint64).reshape(4)
+    _check(ctx.handle, ctx._lib.zg16_prove_from_evals(
+        ctx.handle, dev_key.handle, dev_r1cs.handle, *(x.ctypes.data_as(C.c_void_p) for x in ev), 0,
+        zi.ctypes.data_as(C.c_void_p), za.ctypes.data_as(C.c_void_p) if za.size else None, 0,
+        _lib.as_u64p(r_mont), _lib.as_u64p(s_mont), C.byref(raw)))
+    return Proof(raw)
+
+
 def create_proof(circuit, params, r, s, ctx=None):
     """bellman `create_proof(circuit, params, r, s)`; r, s are canonical integers in Fr."""
     ctx = ctx or Context()

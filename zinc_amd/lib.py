@@ -75,6 +75,8 @@ SYMBOLS = [
     ("zg16_r1cs_density", C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     ("zg16_prove", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                              u64p, u64p, C.POINTER(Proof)]),
+    ("zg16_prove_from_evals", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                        C.c_void_p, C.c_void_p, C.c_int, u64p, u64p, C.POINTER(Proof)]),
     ("zg16_prove_partial", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                      C.POINTER(Partial)]),
     ("zg16_proof_encode", C.c_int, [C.POINTER(Proof), C.POINTER(C.c_uint8)]),
