@@ -89,12 +89,18 @@ def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # one rank per GPU over RCCL; ZG16_DIST_BACKEND=gloo rehearses the same code on a one-GPU box (every
+    # rank on GPU 0, exchanges staged through the host)
+    backend = os.environ.get("ZG16_DIST_BACKEND", "nccl")
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if backend == "nccl" else 0
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     import zinc_amd
@@ -167,7 +173,7 @@ def main():
         ctx.serial(False)
     ctx.profile(False, reset=False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -188,6 +188,19 @@ unsigned    zg16_r1cs_log_domain(const zg16_r1cs* r1cs);
  * coset != 0 selects `coset_fft` / `icoset_fft` (multiplicative generator 7). */
 zg16_status zg16_ntt(zg16_ctx* ctx, uint64_t* data, unsigned log_n, int inverse, int coset,
                      int on_device);
+/* One `EvaluationDomain::fft` / `ifft` of 2^log_n points spread over G = 2^log_shards GPUs (G <= 8) with a
+ * single all-to-all.  bellman_ce has no counterpart (its transform runs on one host's cores); the values are
+ * those of zg16_ntt on the whole vector.
+ *   forward: GPU g holds x[g + G j], j < L = 2^log_n / G.  Each GPU runs zg16_ntt(part, log_n - log_shards, 0, 0, 1);
+ *            an all-to-all with equal splits follows (chunk h of every GPU goes to GPU h, which stores the chunk
+ *            it gets from GPU g at block g); then zg16_ntt_cross(.., inverse = 0) on every GPU.  Block k1 of
+ *            GPU h (L / G elements) then holds X[(h L/G + i) + L k1], i < L / G.
+ *   inverse: from that layout, zg16_ntt_cross(.., inverse = 1), the same all-to-all, then
+ *            zg16_ntt(part, log_n - log_shards, 1, 0, 1); GPU g ends with x[g + G j].  The 1/N is included.
+ * data: this GPU's L elements, transformed in place; device memory when `on_device` is non-zero (what the
+ * exchange delivers), host memory otherwise. */
+zg16_status zg16_ntt_cross(zg16_ctx* ctx, uint64_t* data, unsigned log_n, unsigned log_shards,
+                           unsigned shard, int inverse, int on_device);
 /* H coefficients from row evaluations a, b, c (n_rows each): 3 ifft, 3 coset_fft, pointwise
  * a*b-c, divide by Z on the coset, icoset_fft.  Writes m - 1 Montgomery Fr to h. */
 zg16_status zg16_h_coefficients(zg16_ctx* ctx, const uint64_t* a, const uint64_t* b,

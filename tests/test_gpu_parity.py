@@ -130,6 +130,51 @@ def test_ntt_full_size_properties(gpu_ctx, log_n):
     assert got == want
 
 
+@pytest.mark.parametrize("log_n,world", [(2, 2), (6, 2), (8, 4), (10, 8), (13, 2), (16, 4), (20, 8)])
+def test_ntt_sharded_steps(gpu_ctx, log_n, world):
+    """The transform spread over `world` shards with one exchange: every shard's kernels run back to back on
+    this GPU through the C ABI and numpy plays the all-to-all.  Equals the whole-vector transform (the CPU
+    oracle's up to 2^16, zg16_ntt's above), forward and inverse."""
+    from oracle import cpu_binding as cb
+    from zinc_amd.distributed import ntt_shard_input, ntt_shard_output_index
+    L = gpu_ctx._lib
+    n = 1 << log_n
+    log_g = world.bit_length() - 1
+    rng = np.random.default_rng(log_n * 10 + world)
+    x = rand_fr(rng, n)
+    whole = cb.fft(x, False, False, threads=8) if log_n <= 16 else gpu_ctx.ntt(x)
+    chunk = n // world // world
+
+    def run(parts, inverse):
+        bufs = [np.ascontiguousarray(p, dtype=np.uint64) for p in parts]
+        local = lambda t: L.zg16_ntt(gpu_ctx.handle, t.ctypes.data_as(C.c_void_p), log_n - log_g, inverse, 0, 0)
+        cross = lambda t, g: L.zg16_ntt_cross(gpu_ctx.handle, t.ctypes.data_as(C.c_void_p), log_n, log_g, g, inverse, 0)
+
+        def exchange(ts):
+            host = [t.reshape(world, chunk, 4) for t in ts]
+            return [np.ascontiguousarray(np.stack([host[g][h] for g in range(world)]).reshape(-1, 4)) for h in range(world)]
+        if not inverse:
+            assert all(local(t) == 0 for t in bufs)
+            bufs = exchange(bufs)
+            assert all(cross(t, g) == 0 for g, t in enumerate(bufs))
+        else:
+            assert all(cross(t, g) == 0 for g, t in enumerate(bufs))
+            bufs = exchange(bufs)
+            assert all(local(t) == 0 for t in bufs)
+        return bufs
+
+    got = run([ntt_shard_input(x, g, world) for g in range(world)], 0)
+    for g in range(world):
+        assert np.array_equal(got[g], whole[ntt_shard_output_index(n, g, world)]), ("forward", g)
+    back = run(got, 1)
+    for g in range(world):
+        assert np.array_equal(back[g], ntt_shard_input(x, g, world)), ("inverse", g)
+    # a shard count the split does not allow
+    t = np.zeros((8, 4), dtype=np.uint64)
+    assert L.zg16_ntt_cross(gpu_ctx.handle, t.ctypes.data_as(C.c_void_p), 2, 2, 0, 0, 0) == 5
+    assert L.zg16_ntt_cross(gpu_ctx.handle, t.ctypes.data_as(C.c_void_p), 4, 1, 2, 0, 0) == 5
+
+
 @pytest.mark.parametrize("rows", [3, 6])
 def test_h_poly_golden(gpu_ctx, rows):
     fx = golden("h_poly_%d.json" % rows)
@@ -488,6 +533,34 @@ def test_cpp_host_mirror_driver(gpu_ctx, tmp_path):
 
 
 # ------------------------------------------------------------------------------ multi-process
+def _run_ranks(script, world, port, *args):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root)
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", script), str(r), str(world), str(port)] +
+                              [str(a) for a in args], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=100)[0].decode())
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    return outs
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_transform_over_ranks(world):
+    """`world` processes on one GPU (gloo stands in for RCCL): zinc_amd.distributed.ntt_sharded forward and
+    inverse, equal to zg16_ntt on the whole vector."""
+    outs = _run_ranks("gpu_ntt_worker.py", world, 29550 + world, 14)
+    assert "sharded transform" in outs[0], outs[0]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_prove_with_split_transforms(world):

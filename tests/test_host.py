@@ -146,6 +146,26 @@ def test_two_rank_gloo_gather_and_finish():
     assert "PROOF_MATCH" in outs[0], outs[0]
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_gloo_sharded_transform_schedule(world):
+    """The one-exchange sharded transform over gloo ranks on the CPU: the product's schedule, all-to-all
+    and index maps around CPU stand-ins for the per-rank kernels equal the oracle's whole-vector FFT."""
+    script = os.path.join(ROOT, "tests", "gloo_ntt_worker.py")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    procs = [subprocess.Popen([sys.executable, script, str(r), str(world), str(29560 + world), "8"], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=240)[0].decode())
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "NTT_SHARDED_MATCH" in outs[0], outs[0]
+
+
 def test_fp29_bounds_hold():
     """The lazy 29-bit-limb arithmetic of the multiexp kernels never overflows a column sum, never
     borrows in a limb-wise subtraction and keeps every product below 2p (worst-case propagation)."""

@@ -149,6 +149,7 @@ void zg16_ctx_destroy(zg16_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
   ntt_free_domains(ctx);
+  ntt_free_cross_tables(ctx);
   for (auto& s : ctx->scratch)
     if (s) (void)hipFree(s);
   for (auto& e : ctx->ev)
@@ -677,6 +678,26 @@ zg16_status zg16_ntt(zg16_ctx* ctx, uint64_t* data, unsigned log_n, int inverse,
     ZG_HIP(ctx, hipMemcpyAsync(d, data, bytes, hipMemcpyHostToDevice, ctx->stream));
   }
   ZG_TRY(ntt_device(ctx, d, log_n, inverse != 0, coset != 0));
+  if (!on_device) ZG_HIP(ctx, hipMemcpyAsync(data, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ZG16_OK;
+}
+
+zg16_status zg16_ntt_cross(zg16_ctx* ctx, uint64_t* data, unsigned log_n, unsigned log_shards, unsigned shard,
+                           int inverse, int on_device) {
+  if (!ctx || !data) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "bad arguments to zg16_ntt_cross");
+  if (log_n >= 28) return fail(ctx, ZG16_ERR_POLYNOMIAL_DEGREE_TOO_LARGE, "domain 2^%u exceeds 2^27", log_n);
+  if (log_shards > 3 || 2 * log_shards > log_n || shard >= (1u << log_shards))
+    return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "zg16_ntt_cross: 2^%u points over 2^%u shards (shard %u) is not a valid split",
+                log_n, log_shards, shard);
+  ZG_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t bytes = sizeof(Fr) << (log_n - log_shards);
+  Fr* d = (Fr*)data;
+  if (!on_device) {
+    ZG_TRY(scratch_get(ctx, 4, bytes, (void**)&d));
+    ZG_HIP(ctx, hipMemcpyAsync(d, data, bytes, hipMemcpyHostToDevice, ctx->stream));
+  }
+  ZG_TRY(ntt_cross_device(ctx, d, log_n, log_shards, shard, inverse != 0));
   if (!on_device) ZG_HIP(ctx, hipMemcpyAsync(data, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
   ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return ZG16_OK;

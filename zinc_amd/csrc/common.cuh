@@ -51,6 +51,7 @@ struct zg16_ctx {
   hipEvent_t ev[16] = {};
   std::string last_error = "";
   std::map<unsigned, zg::NttDomain*> domains;  // per log2 size
+  std::map<uint64_t, void*> cross_tables;      // twiddles of the cross-GPU step of a sharded transform
   // grow-only device scratch arenas, one per independent consumer
   void* scratch[10] = {};
   size_t scratch_bytes[10] = {};
@@ -216,5 +217,9 @@ template <class F>
 zg16_status msm_collect(zg16_ctx* ctx, const MsmPending* pend, XYZZ<F>* out);
 
 void ntt_free_domains(zg16_ctx* ctx);
+void ntt_free_cross_tables(zg16_ctx* ctx);
+// The cross-GPU step of a 2^log_n-point transform sharded over 2^log_g GPUs (see ntt.hip), in place on
+// this shard's 2^(log_n - log_g) elements.
+zg16_status ntt_cross_device(zg16_ctx* ctx, Fr* data, unsigned log_n, unsigned log_g, unsigned shard, bool inverse);
 
 }  // namespace zg

@@ -530,4 +530,97 @@ zg16_status h_pipeline_device(zg16_ctx* ctx, Fr* a, Fr* b, Fr* c, unsigned log_m
   return ntt_raw(ctx, d, b, a, true, nullptr, &finish);
 }
 
+// ---- one transform over several GPUs ----------------------------------------------------------
+// N = G * L points over G GPUs (G a power of two, at most 8), one exchange.  GPU g starts with the
+// decimated sequence x[g + G j], j < L.  With k = k2 + L k1:
+//     X[k2 + L k1] = sum_g w_G^(g k1) * ( w_N^(g k2) * Y_g[k2] ),   Y_g = the L-point transform of GPU g's part,
+// so every GPU runs its own L-point transform (ntt_device), the all-to-all hands GPU h the slice
+// k2 in [h L/G, (h+1) L/G) of every Y_g as G blocks, and this kernel applies the twiddle and the G-point
+// transform across the blocks: block k1 of GPU h then holds X[(h L/G + i) + L k1].  The inverse runs
+// the same steps backwards (inverse G-point transform, conjugate twiddle with the 1/G folded in,
+// all-to-all, inverse L-point transform with its 1/L).
+struct CrossRoots {
+  Fr w[4];  // w_G^j (or its inverse), j < G/2
+};
+
+template <int LG>
+__global__ __launch_bounds__(256) void k_ntt_cross(Fr* data, uint32_t blk, const Fr* __restrict__ tw, CrossRoots roots,
+                                                   Fr scale0, int inverse) {
+  constexpr int G = 1 << LG;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= blk) return;
+  Fr y[G];
+#pragma unroll
+  for (int g = 0; g < G; g++) {
+    Fr x = data[(size_t)g * blk + i];
+    if (!inverse && g) x = mul(x, tw[(size_t)(g - 1) * blk + i]);
+    y[__brev((unsigned)g) >> (32 - LG)] = x;
+  }
+#pragma unroll
+  for (int s = 0; s < LG; s++) {
+    const int h = 1 << s;
+#pragma unroll
+    for (int u = 0; u < G / 2; u++) {
+      const int pos = u & (h - 1), i0 = ((u >> s) << (s + 1)) + pos;
+      const Fr t = pos ? mul(y[i0 + h], roots.w[pos << (LG - 1 - s)]) : y[i0 + h];
+      y[i0 + h] = sub(y[i0], t);
+      y[i0] = add(y[i0], t);
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < G; g++) {
+    Fr x = y[g];
+    if (inverse) x = mul(x, g ? tw[(size_t)(g - 1) * blk + i] : scale0);
+    data[(size_t)g * blk + i] = x;
+  }
+}
+
+// The twiddle table of one (size, shard count, shard, direction): [G - 1][L / G] entries
+// w_N^(+-g k2) for k2 in this shard's slice, times 1/G when inverse.  Built on first use and kept.
+void ntt_free_cross_tables(zg16_ctx* ctx) {
+  for (auto& kv : ctx->cross_tables) (void)hipFree(kv.second);
+  ctx->cross_tables.clear();
+}
+
+zg16_status ntt_cross_device(zg16_ctx* ctx, Fr* data, unsigned log_n, unsigned log_g, unsigned shard, bool inverse) {
+  if (log_g == 0) return ZG16_OK;
+  const uint32_t G = 1u << log_g, blk = 1u << (log_n - 2 * log_g);
+  Fr omega = host_root_of_unity();
+  for (unsigned i = log_n; i < 28; i++) omega = sqr(omega);
+  if (inverse) omega = inv(omega);
+  const Fr g_inv = inv(from_u64<FrParams>(G));
+  const uint64_t key = ((uint64_t)log_n << 32) | (log_g << 16) | (shard << 1) | (inverse ? 1 : 0);
+  hipStream_t st = ctx->stream;
+  Fr* tw;
+  auto it = ctx->cross_tables.find(key);
+  if (it != ctx->cross_tables.end()) {
+    tw = (Fr*)it->second;
+  } else {
+    ZG_HIP(ctx, hipMalloc((void**)&tw, (size_t)(G - 1) * blk * sizeof(Fr)));
+    for (uint32_t g = 1; g < G; g++) {
+      const Fr base = pow_u64(omega, g);
+      Fr c = pow_u64(base, (uint64_t)shard * blk);
+      if (inverse) c = mul(c, g_inv);
+      k_pow_table<<<(blk + 4095) / 4096, 256, 0, st>>>(tw + (size_t)(g - 1) * blk, blk, base, c);
+    }
+    ctx->cross_tables[key] = tw;
+  }
+  CrossRoots roots;
+  const Fr wg = pow_u64(omega, (uint64_t)1 << (log_n - log_g));  // w_G (or its inverse)
+  Fr p = Fr::one();
+  for (uint32_t j = 0; j < 4; j++) {
+    roots.w[j] = p;
+    p = mul(p, wg);
+  }
+  const Fr scale0 = inverse ? g_inv : Fr::one();
+  const unsigned grid = (blk + 255) / 256;
+  switch (log_g) {
+    case 1: k_ntt_cross<1><<<grid, 256, 0, st>>>(data, blk, tw, roots, scale0, inverse); break;
+    case 2: k_ntt_cross<2><<<grid, 256, 0, st>>>(data, blk, tw, roots, scale0, inverse); break;
+    default: k_ntt_cross<3><<<grid, 256, 0, st>>>(data, blk, tw, roots, scale0, inverse); break;
+  }
+  ZG_HIP(ctx, hipGetLastError());
+  return ZG16_OK;
+}
+
 }  // namespace zg

@@ -64,6 +64,9 @@ def h_coefficients_split(ctx, mat, z_in_ptr, z_aux_ptr, on_device, rank, world, 
             t.copy_(h)
         else:
             fn(t, peer)
+            # RCCL's wait() only orders torch's current stream after the transfer; the library's kernels
+            # run on its own streams, so the host waits here before handing the buffer over.
+            torch.cuda.current_stream(device).synchronize()
 
     bufs = {}
     for which in range(3):
@@ -116,3 +119,90 @@ def prove_sharded(ctx, key, mat, z_in_ptr, z_aux_ptr, on_device, pk_view, r_mont
     if rank != 0:
         return None
     return finish(pk_view, parts, world, r_mont, s_mont)
+
+
+# ---- one transform over several GPUs --------------------------------------------------------------
+def ntt_shard_input(x, rank, world):
+    """Rank `rank`'s part of a natural-order vector x (rows = elements): x[rank + world * j]."""
+    return x[rank::world]
+
+
+def ntt_shard_output_index(n, rank, world):
+    """Natural-order indices of the elements rank `rank` holds after a forward sharded transform of n
+    points, in the order it holds them: block k1 (of n / world^2 elements) holds
+    X[(rank * blk + i) + (n / world) * k1]."""
+    import numpy as np
+    length = n // world
+    blk = length // world
+    k1 = np.arange(world).reshape(-1, 1)
+    i = np.arange(blk).reshape(1, -1)
+    return (rank * blk + i + length * k1).reshape(-1)
+
+
+def _all_to_all(t, world, device):
+    """Equal-split all-to-all of a (L, 4) int64 tensor: chunk h goes to rank h, which stores what it
+    gets from rank g at chunk g.  RCCL moves device memory; with gloo (CPU rehearsal) the data is staged
+    through the host."""
+    import torch
+    import torch.distributed as dist
+    staged = dist.get_backend() == "gloo"
+    src = t.cpu() if staged else t
+    dst = torch.empty_like(src)
+    try:
+        dist.all_to_all_single(dst, src)
+    except RuntimeError:
+        # a backend without all-to-all: pairwise exchanges
+        ins, outs = list(src.chunk(world)), list(dst.chunk(world))
+        rank = dist.get_rank()
+        outs[rank].copy_(ins[rank])
+        reqs = []
+        for peer in range(world):
+            if peer != rank:
+                reqs.append(dist.isend(ins[peer].contiguous(), peer))
+                reqs.append(dist.irecv(outs[peer], peer))
+        for r in reqs:
+            r.wait()
+    if staged:
+        t.copy_(dst)
+        return t
+    # RCCL's wait() orders only torch's current stream; the library works on its own streams
+    torch.cuda.current_stream(device).synchronize()
+    return dst
+
+
+def ntt_sharded(ctx, part, log_n, rank, world, inverse=False, device=None):
+    """`EvaluationDomain::fft` / `ifft` of 2^log_n points held by `world` ranks (a power of two, at most
+    8), one all-to-all.  part: this rank's 2^log_n / world elements as an (L, 4) int64 device tensor
+    -- x[rank + world * j] going into a forward transform (ntt_shard_input), the layout of
+    ntt_shard_output_index coming out; the inverse maps that layout back.  Returns the transformed
+    tensor (a new one when RCCL moved the data, `part` itself otherwise)."""
+    L = ctx._lib
+    log_g = world.bit_length() - 1
+    assert 1 << log_g == world and world <= 8, "the shard count must be a power of two, at most 8"
+    log_l = log_n - log_g
+    assert part.shape[0] == 1 << log_l and part.is_contiguous()
+
+    def local(t):
+        _check(ctx.handle, L.zg16_ntt(ctx.handle, C.c_void_p(t.data_ptr()), log_l, int(inverse), 0, 1))
+
+    def cross(t):
+        _check(ctx.handle, L.zg16_ntt_cross(ctx.handle, C.c_void_p(t.data_ptr()), log_n, log_g, rank, int(inverse), 1))
+
+    return exchange_schedule(part, world, inverse, local, cross, device)
+
+
+def exchange_schedule(part, world, inverse, local, cross, device=None):
+    """The order of steps of a sharded transform around its one all-to-all; `local` and `cross` transform
+    a tensor in place (the library calls in ntt_sharded; CPU stand-ins in the gloo rehearsal)."""
+    if world == 1:
+        local(part)
+        return part
+    if not inverse:
+        local(part)
+        out = _all_to_all(part, world, device)
+        cross(out)
+    else:
+        cross(part)
+        out = _all_to_all(part, world, device)
+        local(out)
+    return out

@@ -77,6 +77,7 @@ SYMBOLS = [
                              u64p, u64p, C.POINTER(Proof)]),
     ("zg16_prove_from_evals", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                         C.c_void_p, C.c_void_p, C.c_int, u64p, u64p, C.POINTER(Proof)]),
+    ("zg16_ntt_cross", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_int, C.c_int]),
     ("zg16_prove_partial", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                      C.POINTER(Partial)]),
     ("zg16_proof_encode", C.c_int, [C.POINTER(Proof), C.POINTER(C.c_uint8)]),
