@@ -17,11 +17,11 @@ def short(name):
 def main(path, back=1):
     rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), r["Queue_Id"]) for r in csv.DictReader(open(path))]
     rows.sort()
-    # step boundaries: a k_spmv_* launch more than a millisecond after the previous one opens a prove
+    # step boundaries: a k_spmv_* launch more than 0.1 ms after the previous one opens a prove
     starts, last = [], -10**18
     for i, r in enumerate(rows):
         if r[2].startswith("k_spmv"):
-            if r[0] - last > 1000000:
+            if r[0] - last > 100000:
                 starts.append(i)
             last = r[0]
     i0 = starts[-back]

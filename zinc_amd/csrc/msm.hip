@@ -799,7 +799,12 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
   const size_t o_wstd = o;   o += align(nresult * sizeof(XYZZ<F>));  // the result block for the host
   const uint32_t ntiles = (ncount + SCAN_TILE - 1) / SCAN_TILE;
   constexpr uint32_t LP = MsmOps<F>::LP;
-  uint32_t ones_blocks = (uint32_t)((n + 256 * 16 - 1) / (256 * 16));
+  // k_sum_range: sized so that a logical thread adds about 16 bases when half of a group's scalars equal one (a
+  // zinc witness): the workgroup tree that follows costs about a dozen additions per thread, so fewer bases per
+  // thread waste the launch on the tree (2 per thread: proof 3.5 % slower), many more make it a long serial tail
+  constexpr size_t ONES_PER_THREAD = 16;
+  const size_t ones_div = (size_t)sh.G * 2 * (256 / LP) * ONES_PER_THREAD;
+  uint32_t ones_blocks = (uint32_t)((n + ones_div - 1) / ones_div);
   if (ones_blocks > 1024) ones_blocks = 1024;
   const size_t o_tiles = o;  o += align((size_t)(ntiles + 1) * 4);
   const size_t o_part = o;   o += align((size_t)sh.G * ones_blocks * sizeof(PtMem));
