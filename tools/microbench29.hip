@@ -32,6 +32,17 @@ __global__ void k_madd29_chain(XYZZ<Fq>* out, const Affine<Fq>* pts261, int npts
   out[t] = export_xyzz<Fq29Params, FqParams>(a);
 }
 
+// a lone wave walking a chain of dependent full additions, as the bucket-fold kernels do
+__global__ void k_add_full_chain(XYZZ<Fq>* out, const Affine<Fq>* pts261, int npts, int iters) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  G1XYZZ29 a = G1XYZZ29::inf(), b = G1XYZZ29::inf();
+  add_mixed29(a, unpack_affine<Fq29Params>(pts261[t % npts]));
+  add_mixed29(b, unpack_affine<Fq29Params>(pts261[(t + 7) % npts]));
+  add_mixed29(b, unpack_affine<Fq29Params>(pts261[(t + 9) % npts]));
+  for (int i = 0; i < iters; i++) add_full29(a, b);
+  out[t] = export_xyzz<Fq29Params, FqParams>(a);
+}
+
 __global__ void k_madd_chain(XYZZ<Fq>* acc, const Affine<Fq>* pts, int npts, int iters) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   XYZZ<Fq> a = XYZZ<Fq>::inf();
@@ -130,6 +141,24 @@ int main() {
     printf("G1 mixed add (32-bit limbs) : %.3f Gadd/s\n", nthr * 200 / ms / 1e6);
     ms = time_kernel([&] { k_madd29_chain<<<blocks, threads>>>(d1, dp261, npts, 200); });
     printf("G1 mixed add (29-bit limbs) : %.3f Gadd/s\n", nthr * 200 / ms / 1e6);
+  }
+  {
+    const int npts = 4096;
+    G1Affine* dp261; G1XYZZ* d1;
+    CK(hipMalloc(&dp261, npts * sizeof(G1Affine))); CK(hipMalloc(&d1, n * sizeof(G1XYZZ)));
+    std::vector<G1Affine> pts261(npts);
+    G1Affine g = {from_u64<FqParams>(1), from_u64<FqParams>(2)};
+    G1XYZZ acc = G1XYZZ::from_affine(g);
+    for (int i = 0; i < npts; i++) {
+      pts261[i] = to_affine(acc);
+      add_mixed(acc, g);
+      for (int k = 0; k < 5; k++) { pts261[i].x = dbl(pts261[i].x); pts261[i].y = dbl(pts261[i].y); }
+    }
+    CK(hipMemcpy(dp261, pts261.data(), npts * sizeof(G1Affine), hipMemcpyHostToDevice));
+    float ms = time_kernel([&] { k_add_full_chain<<<1, 64>>>(d1, dp261, npts, 200); });
+    printf("lone wave, dependent full additions (hot code): %.2f us each\n", ms * 1e3 / 200);
+    ms = time_kernel([&] { k_add_full_chain<<<1, 64>>>(d1, dp261, npts, 1); });
+    printf("lone wave, kernel with ONE full addition + 3 mixed: %.2f us\n", ms * 1e3);
   }
   printf("done\n");
   return 0;
