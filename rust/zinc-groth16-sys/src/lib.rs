@@ -45,6 +45,14 @@ extern "C" {
     /// (zinc-vm/src/zvm/arguments/command/prove.rs:73-76).
     pub fn zg16_pk_upload_bytes(ctx: *mut zg16_ctx, data: *const u8, len: usize, checked: c_int,
                                 shard_index: c_int, shard_count: c_int, out: *mut *mut zg16_pk) -> c_int;
+    /// For a host that keeps bellman's own `ProvingAssignment`: a, b, c are the evaluation vectors
+    /// `enforce` pushed (n_rows Fr each, the `input_i * 0 = 0` rows included).
+    pub fn zg16_prove_from_evals(ctx: *mut zg16_ctx, pk: *const zg16_pk, r1cs: *const zg16_r1cs,
+                                 a: *const c_void, b: *const c_void, c: *const c_void, evals_on_device: c_int,
+                                 z_in: *const c_void, z_aux: *const c_void, witness_on_device: c_int,
+                                 r: *const u64, s: *const u64, out: *mut zg16_proof) -> c_int;
+    /// bellman `Proof::write` (the 128 bytes `zvm prove` prints as hex, prove.rs:171-174).
+    pub fn zg16_proof_encode(proof: *const zg16_proof, out: *mut u8) -> c_int;
 }
 
 /// Plays the role of bellman's `ProvingAssignment`, but records the matrices instead of evaluating

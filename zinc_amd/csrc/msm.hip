@@ -826,16 +826,8 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
   uint32_t* tiles = (uint32_t*)(base + o_tiles);
   PtMem* ones_part = (PtMem*)(base + o_part);
 
-  // Clearing the counters and bucket sums needs nothing from the stream's earlier work (the scratch slot is
-  // this pipeline's own), so with a side stream it runs there at once instead of behind whatever `st` still
-  // has queued -- for the h query that is the whole transform stage.
-  hipStream_t zs = ms.side ? ms.side : st;
-  ZG_HIP(ctx, hipMemsetAsync(base, 0, o_zero_end, zs));  // every counter and flag
-  ZG_HIP(ctx, hipMemsetAsync(bsum, 0, (size_t)sh.nb * sizeof(PtMem), zs));
-  if (ms.side) {
-    ZG_HIP(ctx, hipEventRecord(ms.ev_join, ms.side));
-    ZG_HIP(ctx, hipStreamWaitEvent(st, ms.ev_join, 0));
-  }
+  ZG_HIP(ctx, hipMemsetAsync(base, 0, o_zero_end, st));  // every counter and flag
+  ZG_HIP(ctx, hipMemsetAsync(bsum, 0, (size_t)sh.nb * sizeof(PtMem), st));
   {
     KernelTimer kt(ctx, K_MSM_DIGITS, (double)n, st);
     const unsigned sgrid = (unsigned)((n + 256 * SORT_TERMS - 1) / (256 * SORT_TERMS));
