@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true",
                     help="leave the per-kernel HIP-event timers off (no roofline in the output): shows what they cost")
+    ap.add_argument("--graph", choices=("auto", "on", "off"), default="auto",
+                    help="HIP-graph replay of the proof (auto: off unless ZG16_GRAPH=1); only proofs without kernel timers replay")
     ap.add_argument("--split-transforms", choices=("auto", "on", "off"), default="auto",
                     help="run the A/B/C transform chains on different ranks (auto: 3+ ranks and 2^22+ rows)")
     return ap.parse_args()
@@ -109,6 +111,7 @@ def main():
     from zinc_amd.groth16 import _check
 
     ctx = zinc_amd.Context(local_rank)
+    ctx.graph({"auto": None, "on": True, "off": False}[args.graph])
     L = ctx._lib
     n_rows = 1 << args.log_rows
     t0 = time.time()

@@ -149,6 +149,19 @@ zg16_status zg16_prove_from_evals(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r
                                   int witness_on_device, const uint64_t r[4], const uint64_t s[4],
                                   zg16_proof* out);
 
+/* Graph replay (opt-in).  A proof is a fixed sequence of launches for a given key and set of matrices (grids are
+ * sized for the worst case and read the actual counts on the device), so zg16_prove / zg16_prove_partial can capture
+ * it into a HIP graph the second time they see a (key, matrices) pair and replay it afterwards: one call queues the
+ * whole proof.  mode 1: on; 0: off; -1 (default): on only if the ZG16_GRAPH environment variable is 1.  It is off
+ * by default because replay measured slower than plain multi-stream launches on MI355X / ROCm 7.2 (the graph's
+ * branches overlap less than the streams do).  Graphs are dropped when a handle is freed.  Per-kernel timing
+ * (zg16_profile_enable) needs plain launches: with profiling on no graph is used; a replayed proof reports only
+ * total_ms in zg16_last_timings.  No counterpart upstream. */
+zg16_status zg16_graph_mode(zg16_ctx* ctx, int mode);
+/* Proofs captured, proofs replayed, captures that failed (those pairs stay on plain launches) since the context
+ * was created; any pointer may be NULL. */
+zg16_status zg16_graph_counts(const zg16_ctx* ctx, uint64_t* captures, uint64_t* replays, uint64_t* failures);
+
 /* bellman `Proof::write`: the 128 bytes whose hex `zvm prove` prints
  * (zinc-vm/src/zvm/arguments/command/prove.rs:171-174).  Host arithmetic only. */
 zg16_status zg16_proof_encode(const zg16_proof* proof, uint8_t out[128]);

@@ -424,6 +424,48 @@ def test_prove_vs_cpu_oracle(gpu_ctx, log_rows, dense):
     mat.free()
 
 
+@pytest.mark.parametrize("log_rows", [8, 13])
+def test_graph_replay_gives_the_same_proofs(gpu_ctx, log_rows):
+    """A proof replayed as a captured HIP graph equals the plainly launched one: first call plain, second captured,
+    later ones replayed -- with a different witness and different r, s each time (the witness is staged outside the
+    graph); a larger proof in between moves the scratch arenas and forces a new capture."""
+    from zinc_amd import workload
+    toxic = dict(k1=3, k2=5, alpha=7, beta=11, gamma=13, delta=17, tau=29 + log_rows)
+    circs = [workload.SyntheticCircuit(1 << log_rows, n_pub=4, seed=(log_rows, 1, 2, 3))]
+    params = workload.generate_parameters(gpu_ctx, circs[0], toxic)
+    key, mat = params.upload(gpu_ctx), circs[0].r1cs().upload(gpu_ctx)
+    zi, za = circs[0].witness()
+    # other satisfying witnesses of the same matrices do not exist for free; other (r, s) pairs and a perturbed
+    # witness (the prover does not check satisfaction) exercise the same data paths
+    zb = za.copy()
+    zb[: len(zb) // 2] = za[len(za) // 2: len(za) // 2 + len(zb) // 2]
+    cases = [(za, 11, 12), (za, 13, 14), (zb, 15, 16), (za, 17, 18), (zb, 19, 20), (za, 21, 22)]
+    gpu_ctx.graph(False)
+    want = [prove_recorded(gpu_ctx, key, mat, zi, w, *ints_to_mont([r, s], R_MOD)).as_tuple() for w, r, s in cases]
+    gpu_ctx.graph(True)
+    c0, r0, f0 = gpu_ctx.graph_counts()
+    try:
+        got = []
+        for k, (w, r, s) in enumerate(cases):
+            if k == 4:  # grow the scratch arenas: the captured graph must not be replayed on stale pointers
+                big = workload.SyntheticCircuit(1 << (log_rows + 2), n_pub=4, seed=(9, 9, 9, 9))
+                bp = workload.generate_parameters(gpu_ctx, big, toxic)
+                bk, bm = bp.upload(gpu_ctx), big.r1cs().upload(gpu_ctx)
+                bzi, bza = big.witness()
+                prove_recorded(gpu_ctx, bk, bm, bzi, bza, *ints_to_mont([1, 2], R_MOD))
+                bk.free()
+                bm.free()
+            got.append(prove_recorded(gpu_ctx, key, mat, zi, w, *ints_to_mont([r, s], R_MOD)).as_tuple())
+        assert got == want
+        c1, r1, f1 = gpu_ctx.graph_counts()
+        # plain, capture + replay, replay, replay | (arenas moved) capture + replay, replay
+        assert (c1 - c0, r1 - r0, f1 - f0) == (2, 5, 0)
+    finally:
+        gpu_ctx.graph(None)
+    key.free()
+    mat.free()
+
+
 def test_prove_full_size_verifies(gpu_ctx):
     """2^20 rows (the benchmark workload): the proof satisfies the Groth16 pairing equation, is
     reproducible, and changes with r."""

@@ -16,7 +16,43 @@
 
 using namespace zg;
 
+// A proof captured as a HIP graph: every launch, memset and result copy of the three multiexp pipelines, the row
+// evaluation and the transforms, across the context's streams; replaying it hands the whole proof (~100 short
+// launches) to the GPU in one call.  Opt-in: see graph_wanted for what it measures like.
+struct zg::ProveGraph {
+  hipGraphExec_t exec = nullptr;
+  MsmPending pend_g2, pend_z, pend_h;
+  uint64_t scratch_gen = 0;
+  int seen = 0;        // proofs of this (key, matrices) pair so far; the second one is captured
+  bool unusable = false;  // capture or instantiation failed once: stay on plain launches
+};
+
 namespace {
+
+void drop_graphs(zg16_ctx* ctx, const void* handle) {
+  for (auto it = ctx->graphs.begin(); it != ctx->graphs.end();) {
+    if (!handle || it->first.first == handle || it->first.second == handle) {
+      if (it->second->exec) (void)hipGraphExecDestroy(it->second->exec);
+      delete it->second;
+      it = ctx->graphs.erase(it);
+    } else {
+      ++it;
+    }
+  }
+}
+
+// Off unless asked for (zg16_graph_mode, or ZG16_GRAPH=1): with ROCm 7.2 on MI355X a replayed proof is SLOWER than
+// the plainly launched one at every size measured (2^8 rows: 1.22 ms against 1.02 ms; 2^20: 5.99 against 4.39) --
+// the runtime runs the graph's four branches with little of the overlap the streams get, and the proof is bound by
+// the GPU-side chains of dependent kernels, not by the host's queueing (0.3 ms, overlapped).
+bool graph_wanted(const zg16_ctx* ctx, unsigned) {
+  int mode = ctx->graph_mode;
+  if (mode < 0) {
+    static const int env = getenv("ZG16_GRAPH") ? atoi(getenv("ZG16_GRAPH")) : 0;
+    mode = env;
+  }
+  return mode > 0;
+}
 
 constexpr uint32_t AUX_BIT = 0x80000000u;
 
@@ -148,6 +184,7 @@ void zg16_ctx_destroy(zg16_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
+  drop_graphs(ctx, nullptr);
   ntt_free_domains(ctx);
   ntt_free_cross_tables(ctx);
   for (auto& s : ctx->scratch)
@@ -210,7 +247,10 @@ zg16_status zg16_pk_upload(zg16_ctx* ctx, const zg16_pk_view* v, int shard_index
 
 void zg16_pk_free(zg16_pk* pk) {
   if (!pk) return;
-  if (pk->ctx) (void)hipSetDevice(pk->ctx->device);
+  if (pk->ctx) {
+    (void)hipSetDevice(pk->ctx->device);
+    drop_graphs(pk->ctx, pk);
+  }
   (void)hipFree(pk->h); (void)hipFree(pk->l); (void)hipFree(pk->a); (void)hipFree(pk->b1); (void)hipFree(pk->b2);
   delete pk;
 }
@@ -286,7 +326,10 @@ zg16_status zg16_r1cs_upload(zg16_ctx* ctx, const zg16_r1cs_view* v, zg16_r1cs**
 
 void zg16_r1cs_free(zg16_r1cs* r) {
   if (!r) return;
-  if (r->ctx) (void)hipSetDevice(r->ctx->device);
+  if (r->ctx) {
+    (void)hipSetDevice(r->ctx->device);
+    drop_graphs(r->ctx, r);
+  }
   for (auto& m : r->m) {
     (void)hipFree(m.row_ptr); (void)hipFree(m.col); (void)hipFree(m.coeff); (void)hipFree(m.long_rows);
   }
@@ -375,7 +418,7 @@ static zg16_status prove_partial_impl(zg16_ctx* ctx, const zg16_pk* pk, const zg
               std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_entry).count(), what);
   };
   // Stage boundaries are events; nothing below waits on the host until every kernel is enqueued.
-  enum { E_BEGIN, E_Z, E_SPMV, E_NTT, E_G1, E_G2_BEGIN, E_G2_END, E_END, E_Z_END = 14 };
+  enum { E_BEGIN, E_Z, E_SPMV, E_NTT, E_G1, E_G2_BEGIN, E_G2_END, E_END, E_Z_END = 14, E_GRAPH_END = 15 };
   hipEvent_t* ev = ctx->ev;
   // ZG16_SERIAL=1 puts every stage on the main stream: slower, but per-kernel timings are then free of
   // contention between the pipelines (used for the uncontended roofline figures)
@@ -384,6 +427,7 @@ static zg16_status prove_partial_impl(zg16_ctx* ctx, const zg16_pk* pk, const zg
   hipStream_t st = ctx->stream, aux = serial ? st : ctx->aux_stream;
   const size_t m = (size_t)1 << r->log_m;
   const uint32_t tc = pk->table_c;
+  const bool tables = tc != 0;
   auto stride = [&](size_t lo, size_t hi) { return tc ? hi - lo : (size_t)0; };
 
   ZG_HIP(ctx, hipEventRecord(ev[E_BEGIN], st));
@@ -398,15 +442,18 @@ static zg16_status prove_partial_impl(zg16_ctx* ctx, const zg16_pk* pk, const zg
       for (Fr* p : {a, b, c}) ZG_HIP(ctx, hipMemsetAsync(p + r->n_rows, 0, (m - r->n_rows) * sizeof(Fr), st));
   }
   const Fr* h_coeffs = h_external ? h_external : a;
+  MsmPending pend_g2, pend_z, pend_h;
+  G1XYZZ g1[3];
+  // Everything from here to E_END is queued without the host waiting on anything, so it can also be captured
+  // into a graph once and replayed.
+  auto enqueue = [&]() -> zg16_status {
   ZG_HIP(ctx, hipEventRecord(ev[E_Z], st));
 
   // Three multiexp pipelines.  The G2 multiexp and the G1 queries over the witness (l, a, b_g1) need
   // only z: they start now on their own streams and run beside the row evaluation and the transforms.
   // The h query needs the H coefficients and follows the transforms on the main stream; the
   // latency-bound ends of the early pipelines then hide under its accumulation.
-  MsmPending pend_g2, pend_z, pend_h;
   char* pinned = (char*)ctx->pinned;
-  const bool tables = tc != 0;
   // h covers coefficients 0..m-2; this shard owns [lo_h, hi_h) clipped to that range
   const size_t hi_h = pk->hi_h < m - 1 ? pk->hi_h : m - 1;
   const size_t lo_h = pk->lo_h < hi_h ? pk->lo_h : hi_h;
@@ -448,7 +495,6 @@ static zg16_status prove_partial_impl(zg16_ctx* ctx, const zg16_pk* pk, const zg
     ZG_HIP(ctx, hipEventRecord(ev[E_Z_END], early));
   }
 
-  G1XYZZ g1[3];
   if (tables) {
     const MsmStreams ms = {st, serial ? nullptr : ctx->side_stream, ev[8], ev[9]};
     ZG_TRY(msm_launch<Fq>(ctx, ms, 1, pinned, &job_h, 1, 1, &pend_h));
@@ -464,9 +510,80 @@ static zg16_status prove_partial_impl(zg16_ctx* ctx, const zg16_pk* pk, const zg
   }
   ZG_HIP(ctx, hipStreamWaitEvent(st, ev[E_G2_END], 0));
   ZG_HIP(ctx, hipEventRecord(ev[E_END], st));
+  return ZG16_OK;
+  };  // enqueue
+
+  // Graph replay: the first proof of a (key, matrices) pair runs as plain launches (and sizes every scratch arena),
+  // the second is captured, later ones are one hipGraphLaunch.  Per-kernel timers need real events between the
+  // launches, so profiling keeps the plain path.
+  ProveGraph* pg = nullptr;
+  bool graphed = false;
+  if (tables && !h_external && !evals && !serial && !ctx->profile && st == ctx->own_stream && graph_wanted(ctx, r->log_m)) {
+    ProveGraph*& slot = ctx->graphs[{pk, r}];
+    if (!slot) slot = new ProveGraph();
+    pg = slot;
+  }
+  if (pg && pg->exec && pg->scratch_gen != ctx->scratch_gen) {  // an arena moved since the capture
+    (void)hipGraphExecDestroy(pg->exec);
+    pg->exec = nullptr;
+  }
+  if (pg && !pg->exec && !pg->unusable && pg->seen >= 1) {
+    ctx->capturing = true;
+    hipGraph_t graph = nullptr;
+    hipError_t ce = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+    const zg16_status es = ce == hipSuccess ? enqueue() : ZG16_ERR_DEVICE;
+    if (ce == hipSuccess) ce = hipStreamEndCapture(st, &graph);
+    ctx->capturing = false;
+    if (es == ZG16_OK && ce == hipSuccess && graph && hipGraphInstantiate(&pg->exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+      pg->pend_g2 = pend_g2; pg->pend_z = pend_z; pg->pend_h = pend_h;
+      pg->scratch_gen = ctx->scratch_gen;
+      ctx->graph_captures++;
+    } else {
+      (void)hipGetLastError();
+      pg->exec = nullptr;
+      pg->unusable = true;
+      ctx->graph_failures++;
+    }
+    if (graph) (void)hipGraphDestroy(graph);
+    mark("proof captured");
+  }
+  if (pg && pg->exec) {
+    pend_g2 = pg->pend_g2; pend_z = pg->pend_z; pend_h = pg->pend_h;
+    ZG_HIP(ctx, hipGraphLaunch(pg->exec, st));
+    ZG_HIP(ctx, hipEventRecord(ev[E_GRAPH_END], st));
+    graphed = true;
+    ctx->graph_replays++;
+  } else {
+    if (pg) pg->seen++;
+    ZG_TRY(enqueue());
+  }
   mark("everything enqueued");
   G2XYZZ qb2;
   bool early_done = false;
+  if (graphed) {
+    // events inside a graph are only edges: the host cannot wait on the early pipelines one by one
+    if (early) early->key_terms();
+    hipError_t q;
+    while ((q = hipEventQuery(ev[E_GRAPH_END])) == hipErrorNotReady) __builtin_ia32_pause();
+    ZG_HIP(ctx, q);
+    mark("GPU idle");
+    G1XYZZ h_sum;
+    ZG_TRY(msm_collect<Fq>(ctx, &pend_z, g1));
+    ZG_TRY(msm_collect<Fq2>(ctx, &pend_g2, &qb2));
+    ZG_TRY(msm_collect<Fq>(ctx, &pend_h, &h_sum));
+    add_full(g1[0], h_sum);
+    if (early) {
+      early->with_g1(g1[1], g1[2]);
+      early->with_g2(qb2);
+    }
+    memcpy(out->hl, &g1[0], sizeof g1[0]);
+    memcpy(out->a, &g1[1], sizeof g1[1]);
+    memcpy(out->b1, &g1[2], sizeof g1[2]);
+    memcpy(out->b2, &qb2, sizeof qb2);
+    ZG_HIP(ctx, hipEventElapsedTime(&tm.total_ms, ev[E_BEGIN], ev[E_GRAPH_END]));
+    mark("multiexps collected");
+    return ZG16_OK;
+  }
   if (tables && early) {
     early->key_terms();  // host work while the GPU is busy
     ZG_HIP(ctx, hipEventSynchronize(ev[E_Z_END]));
@@ -629,6 +746,20 @@ static const char* const kKernelNames[K_COUNT] = {
     "k_spmv_short+long", "k_ntt_pass", "k_scale_powers", "k_mul_sub_scale", "k_sort_*+k_fine_*+k_scan_*", "k_scan",
     "k_accumulate<G1>", "k_accumulate<G2>", "k_combine+k_heavy<G1>", "k_combine+k_heavy<G2>",
     "k_split_sums<G1>", "k_split_sums<G2>", "k_sum_range<G1>", "k_sum_range<G2>"};
+
+zg16_status zg16_graph_mode(zg16_ctx* ctx, int mode) {
+  if (!ctx) return ZG16_ERR_INVALID_ARGUMENT;
+  ctx->graph_mode = mode < 0 ? -1 : (mode != 0);
+  return ZG16_OK;
+}
+
+zg16_status zg16_graph_counts(const zg16_ctx* ctx, uint64_t* captures, uint64_t* replays, uint64_t* failures) {
+  if (!ctx) return ZG16_ERR_INVALID_ARGUMENT;
+  if (captures) *captures = ctx->graph_captures;
+  if (replays) *replays = ctx->graph_replays;
+  if (failures) *failures = ctx->graph_failures;
+  return ZG16_OK;
+}
 
 zg16_status zg16_profile_enable(zg16_ctx* ctx, int on) {
   if (!ctx) return ZG16_ERR_INVALID_ARGUMENT;

@@ -14,6 +14,7 @@
 namespace zg {
 
 struct NttDomain;   // ntt.hip
+struct ProveGraph;  // api.hip: a captured proof (hipGraphExec_t and what the host needs to read its results)
 
 }  // namespace zg
 
@@ -52,6 +53,14 @@ struct zg16_ctx {
   std::string last_error = "";
   std::map<unsigned, zg::NttDomain*> domains;  // per log2 size
   std::map<uint64_t, void*> cross_tables;      // twiddles of the cross-GPU step of a sharded transform
+  // Proofs replayed as HIP graphs, per (key, matrices) pair.  Every device buffer a proof touches belongs to the
+  // context, the key or the matrices, so a captured proof stays valid until one of the scratch arenas moves
+  // (scratch_gen) or a handle is freed.
+  std::map<std::pair<const void*, const void*>, zg::ProveGraph*> graphs;
+  uint64_t scratch_gen = 0;
+  bool capturing = false;  // a stream capture is open: nothing may allocate
+  uint64_t graph_captures = 0, graph_replays = 0, graph_failures = 0;
+  int graph_mode = -1;     // 1: replay every proof as a graph, 0: never, -1: as ZG16_GRAPH says (default: small domains)
   // grow-only device scratch arenas, one per independent consumer
   void* scratch[10] = {};
   size_t scratch_bytes[10] = {};
@@ -87,6 +96,8 @@ inline zg16_status fail(zg16_ctx* ctx, zg16_status st, const char* fmt, ...) {
 // Grow-only scratch arena `slot` of at least `bytes`.
 inline zg16_status scratch_get(zg16_ctx* ctx, int slot, size_t bytes, void** out) {
   if (ctx->scratch_bytes[slot] < bytes) {
+    if (ctx->capturing) return fail(ctx, ZG16_ERR_DEVICE, "scratch arena %d would have to grow during a stream capture", slot);
+    ctx->scratch_gen++;
     if (ctx->scratch[slot]) {
       ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
       ZG_HIP(ctx, hipFree(ctx->scratch[slot]));

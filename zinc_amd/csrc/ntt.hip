@@ -336,6 +336,7 @@ static zg16_status get_domain(zg16_ctx* ctx, unsigned log_n, NttDomain** out) {
     return ZG16_OK;
   }
   if (log_n >= 28) return fail(ctx, ZG16_ERR_POLYNOMIAL_DEGREE_TOO_LARGE, "domain 2^%u exceeds 2^27", log_n);
+  if (ctx->capturing) return fail(ctx, ZG16_ERR_DEVICE, "NTT tables for 2^%u would have to be built during a stream capture", log_n);
   NttDomain* d = new NttDomain();
   d->log_n = log_n;
   d->plan = make_plan(log_n);

@@ -69,6 +69,17 @@ class Context:
         """True: proves issue every stage on one stream (uncontended per-kernel timings); False: overlapped."""
         _check(self.handle, self._lib.zg16_profile_serial(self.handle, int(on)))
 
+    def graph(self, mode):
+        """zg16_graph_mode: True replays every proof as a HIP graph, False never, None the default (off unless
+        ZG16_GRAPH=1; replay measured slower than plain multi-stream launches)."""
+        _check(self.handle, self._lib.zg16_graph_mode(self.handle, -1 if mode is None else int(bool(mode))))
+
+    def graph_counts(self):
+        """(captures, replays, failed captures) since the context was created."""
+        c, r, f = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _check(self.handle, self._lib.zg16_graph_counts(self.handle, C.byref(c), C.byref(r), C.byref(f)))
+        return c.value, r.value, f.value
+
     def kernel_stats(self):
         """{kernel name: (total_ms, launches, units)} since the last reset."""
         out = {}

@@ -77,6 +77,8 @@ SYMBOLS = [
                              u64p, u64p, C.POINTER(Proof)]),
     ("zg16_prove_from_evals", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                         C.c_void_p, C.c_void_p, C.c_int, u64p, u64p, C.POINTER(Proof)]),
+    ("zg16_graph_mode", C.c_int, [C.c_void_p, C.c_int]),
+    ("zg16_graph_counts", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("zg16_ntt_cross", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_int, C.c_int]),
     ("zg16_prove_partial", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                      C.POINTER(Partial)]),
