@@ -48,6 +48,17 @@ def mul_pair(a, b, ks):
     return V(1 + C * s, STRICT)
 
 
+def mul_sub(a, b, c, d, ks):
+    """a*b + (KS - c)*d in one column scan with one reduction"""
+    assert c.L <= KS_MIN, "KS does not dominate limbs"
+    assert ks >= c.v + MARGIN, "KS%d does not dominate value %.2f" % (ks, c.v)
+    assert d.L <= NORM, "d must be normalised"
+    assert 9 * a.L * b.L + 9 * KS_MAX * d.L + 9 * STRICT * STRICT + (1 << 36) < 1 << 64, "column overflow"
+    s = a.v * b.v + ks * d.v
+    assert s <= 169.0, "fused product operands too large: %.1f" % s
+    return V(1 + C * s, STRICT)
+
+
 def sub_k(a, b, k):
     assert b.L <= K_MIN and k >= b.v + MARGIN, "K%d does not dominate (%.2f)" % (k, b.v)
     assert a.L + K_MAX < 1 << 32
@@ -87,7 +98,7 @@ def g1_madd(acc, bx, by):
     r = sub_k(s2, acc.y, 6); sqr(r)
     ppp = mul(pp_, pp); q = mul(acc.x, pp)
     x3 = sub2_k(sqr(r), ppp, q, 6); t = sub_k(q, x3, 8)
-    y3 = sub_k(mul(r, t), mul(acc.y, ppp), 3)
+    y3 = mul_sub(r, t, acc.y, ppp, 6)
     return Pt(x3, y3, mul(acc.zz, pp), mul(acc.zzz, ppp))
 
 
@@ -96,7 +107,7 @@ def g1_add(a, p):
     pp_ = sub_k(u2, u1, 3); pp = sqr(pp_); r = sub_k(s2, s1, 3); sqr(r)
     ppp = mul(pp_, pp); q = mul(u1, pp)
     x3 = sub2_k(sqr(r), ppp, q, 6); t = sub_k(q, x3, 8)
-    y3 = sub_k(mul(r, t), mul(s1, ppp), 3)
+    y3 = mul_sub(r, t, s1, ppp, 2)
     return Pt(x3, y3, mul(mul(a.zz, p.zz), pp), mul(mul(a.zzz, p.zzz), ppp))
 
 

@@ -81,7 +81,7 @@ ZG_D void add_mixed29(XYZZ29<P>& acc, const Affine29<P>& p) {
   const F q = mul(acc.x, pp);                     // <2
   const F x3 = sub2_k(sqr(r), ppp, q, P::K6);     // r^2 - ppp - 2q : < 2 + 6 = 8
   const F t = sub_k(q, x3, P::K8);                // <10
-  const F y3 = sub_k(mul(r, t), mul(acc.y, ppp), P::K3);  // 80, 10 -> < 5
+  const F y3 = mul_sub(r, t, acc.y, ppp, P::KS6); // r*t - y*ppp in one scan: 80 + 6*2 -> <2
   acc.x = x3;
   acc.y = y3;
   acc.zz = mul(acc.zz, pp);
@@ -116,7 +116,7 @@ ZG_D void add_full29(XYZZ29<P>& acc, const XYZZ29<P>& p) {
   const F q = mul(u1, pp);
   const F x3 = sub2_k(sqr(r), ppp, q, P::K6);     // <8
   const F t = sub_k(q, x3, P::K8);                // <10
-  const F y3 = sub_k(mul(r, t), mul(s1, ppp), P::K3);  // <5
+  const F y3 = mul_sub(r, t, s1, ppp, P::KS2);    // r*t - s1*ppp in one scan: 50 + 2*2 -> <2
   acc.x = x3;
   acc.y = y3;
   acc.zz = mul(mul(acc.zz, p.zz), pp);

@@ -165,6 +165,44 @@ ZG_D Fp29<P> sqr(const Fp29<P>& a) {
   return r;
 }
 
+// (a*b - c*d) * 2^-261 mod p as ONE column scan with one Montgomery reduction: a*b + (KS - c)*d, where KS (one of
+// P::KS*) is a multiple of p that dominates c limb by limb and in value.  Saves the second product's 81
+// reduction multiply-adds.  Result below 2p with normalised limbs when
+// (bound of a)*(bound of b) + (KS / p)*(bound of d) <= 169; c, d must have normalised limbs.
+template <class P>
+ZG_D Fp29<P> mul_sub(const Fp29<P>& a, const Fp29<P>& b, const Fp29<P>& c, const Fp29<P>& d, const uint32_t (&KS)[9]) {
+  uint32_t z[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) z[i] = KS[i] - c.v[i];
+  uint32_t m[9];
+  Fp29<P> r;
+  uint64_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < 17; k++) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      const int j = k - i;
+      if (j >= 0 && j < 9) {
+        acc = mad64(a.v[i], b.v[j], acc);
+        acc = mad64(z[i], d.v[j], acc);
+      }
+    }
+    if (k < 9) {
+#pragma unroll
+      for (int i = 0; i < k; i++) acc = mad64(m[i], P::MOD[k - i], acc);
+      m[k] = ((uint32_t)acc * P::INV) & MASK29;
+      acc = mad64(m[k], P::MOD[0], acc);
+    } else {
+#pragma unroll
+      for (int i = k - 8; i < 9; i++) acc = mad64(m[i], P::MOD[k - i], acc);
+      r.v[k - 9] = (uint32_t)acc & MASK29;
+    }
+    acc >>= 29;
+  }
+  r.v[8] = (uint32_t)acc;
+  return r;
+}
+
 // ---- Fq2 = Fq[u]/(u^2 + 1) spread over a lane pair ---------------------------------------------------
 // Lane 2k holds the real component of every Fq2 value, lane 2k+1 the imaginary one.  Additions
 // and subtractions are the single-lane ones; a product needs the partner's components, fetched
