@@ -58,12 +58,16 @@ constexpr uint32_t AUX_BIT = 0x80000000u;
 
 // Upload `count` points as window 0 of a table of `windows` windows and fill the other windows.
 template <class F>
-zg16_status upload_query(zg16_ctx* ctx, Affine<F>** dst, const void* src, size_t count, uint32_t table_c) {
+zg16_status upload_query(zg16_ctx* ctx, Affine<F>** dst, const void* src, size_t count, uint32_t table_c,
+                         Affine<F>** direct) {
   *dst = nullptr;
+  *direct = nullptr;
   if (!count) return ZG16_OK;
   const size_t windows = table_c ? msm_table_windows(table_c) : 1;
   ZG_HIP(ctx, hipMalloc((void**)dst, windows * count * sizeof(Affine<F>)));
   ZG_HIP(ctx, hipMemcpy(*dst, src, count * sizeof(Affine<F>), hipMemcpyHostToDevice));
+  // small queries also get a direct table of every multiple a digit can ask for (built from the ABI-form points)
+  if (table_c) ZG_TRY(msm_build_direct<F>(ctx, *dst, count, direct));
   // fills the other windows (if any) and rewrites every point in the multiexp kernels' packed form
   ZG_TRY(msm_build_table<F>(ctx, *dst, count, table_c));
   return ZG16_OK;
@@ -231,16 +235,17 @@ zg16_status zg16_pk_upload(zg16_ctx* ctx, const zg16_pk_view* v, int shard_index
   pk->table_c = msm_table_window(largest, 1);
   pk->table_c_h = msm_table_window(pk->hi_h - pk->lo_h, 0);
   pk->table_c_g2 = msm_table_window(pk->hi_b - pk->lo_b, 2);
-  ZG_TRY(upload_query<Fq>(ctx, &pk->h, v->h + 8 * pk->lo_h, pk->hi_h - pk->lo_h, pk->table_c_h));
-  ZG_TRY(upload_query<Fq>(ctx, &pk->l, v->l + 8 * pk->lo_l, pk->hi_l - pk->lo_l, pk->table_c));
-  ZG_TRY(upload_query<Fq>(ctx, &pk->a, v->a + 8 * pk->lo_a, pk->hi_a - pk->lo_a, pk->table_c));
-  ZG_TRY(upload_query<Fq>(ctx, &pk->b1, v->b_g1 + 8 * pk->lo_b, pk->hi_b - pk->lo_b, pk->table_c));
-  ZG_TRY(upload_query<Fq2>(ctx, &pk->b2, v->b_g2 + 16 * pk->lo_b, pk->hi_b - pk->lo_b, pk->table_c_g2));
+  ZG_TRY(upload_query<Fq>(ctx, &pk->h, v->h + 8 * pk->lo_h, pk->hi_h - pk->lo_h, pk->table_c_h, &pk->h_d));
+  ZG_TRY(upload_query<Fq>(ctx, &pk->l, v->l + 8 * pk->lo_l, pk->hi_l - pk->lo_l, pk->table_c, &pk->l_d));
+  ZG_TRY(upload_query<Fq>(ctx, &pk->a, v->a + 8 * pk->lo_a, pk->hi_a - pk->lo_a, pk->table_c, &pk->a_d));
+  ZG_TRY(upload_query<Fq>(ctx, &pk->b1, v->b_g1 + 8 * pk->lo_b, pk->hi_b - pk->lo_b, pk->table_c, &pk->b1_d));
+  ZG_TRY(upload_query<Fq2>(ctx, &pk->b2, v->b_g2 + 16 * pk->lo_b, pk->hi_b - pk->lo_b, pk->table_c_g2, &pk->b2_d));
   memcpy(&pk->alpha_g1, v->alpha_g1, 64);
   memcpy(&pk->beta_g1, v->beta_g1, 64);
   memcpy(&pk->delta_g1, v->delta_g1, 64);
   memcpy(&pk->beta_g2, v->beta_g2, 128);
   memcpy(&pk->delta_g2, v->delta_g2, 128);
+  pk->build_delta_tables();
   *out = pk.release();
   return ZG16_OK;
 }
@@ -252,6 +257,7 @@ void zg16_pk_free(zg16_pk* pk) {
     drop_graphs(pk->ctx, pk);
   }
   (void)hipFree(pk->h); (void)hipFree(pk->l); (void)hipFree(pk->a); (void)hipFree(pk->b1); (void)hipFree(pk->b2);
+  (void)hipFree(pk->h_d); (void)hipFree(pk->l_d); (void)hipFree(pk->a_d); (void)hipFree(pk->b1_d); (void)hipFree(pk->b2_d);
   delete pk;
 }
 
@@ -359,11 +365,13 @@ struct Assembly {
   Fr rc, sc;  // canonical r, s
   G1XYZZ A, c_part;
   G2XYZZ B;
+  const FixedBaseTable<Fq>* delta1_table = nullptr;   // optional (a key handle has them)
+  const FixedBaseTable<Fq2>* delta2_table = nullptr;
   // needs nothing from the GPU: alpha + r*delta and beta + s*delta
   void key_terms() {
-    A = scalar_mul_w4(G1XYZZ::from_affine(delta1), rc.v);
+    A = delta1_table ? delta1_table->mul(rc.v) : scalar_mul_w4(G1XYZZ::from_affine(delta1), rc.v);
     add_mixed(A, alpha1);
-    B = scalar_mul_w4(G2XYZZ::from_affine(delta2), sc.v);
+    B = delta2_table ? delta2_table->mul(sc.v) : scalar_mul_w4(G2XYZZ::from_affine(delta2), sc.v);
     add_mixed(B, beta2);
   }
   void with_g2(const G2XYZZ& qb2) { add_full(B, qb2); }
@@ -371,8 +379,7 @@ struct Assembly {
     add_full(A, qa);
     G1XYZZ b1 = qb1;
     add_mixed(b1, beta1);
-    c_part = scalar_mul_w4(A, sc.v);
-    add_full(c_part, scalar_mul_w4(b1, rc.v));
+    c_part = double_scalar_mul(A, sc.v, b1, rc.v);
   }
   void early(const G1XYZZ& qa, const G1XYZZ& qb1, const G2XYZZ& qb2) {
     key_terms();
@@ -458,11 +465,12 @@ static zg16_status prove_partial_impl(zg16_ctx* ctx, const zg16_pk* pk, const zg
   const size_t hi_h = pk->hi_h < m - 1 ? pk->hi_h : m - 1;
   const size_t lo_h = pk->lo_h < hi_h ? pk->lo_h : hi_h;
   // the h table is laid out for the whole shard; skip the points below lo_h when the range was clipped
-  const MsmJob<Fq> job_h = {pk->h + (lo_h - pk->lo_h), h_coeffs + lo_h, nullptr, hi_h - lo_h, stride(pk->lo_h, pk->hi_h), pk->table_c_h, 0};
+  const MsmJob<Fq> job_h = {pk->h + (lo_h - pk->lo_h), h_coeffs + lo_h, nullptr, hi_h - lo_h, stride(pk->lo_h, pk->hi_h), pk->table_c_h, 0,
+                            pk->h_d ? pk->h_d + (lo_h - pk->lo_h) : nullptr};
   const MsmJob<Fq> jobs_z[3] = {
-      {pk->l, z + r->n_in + pk->lo_l, nullptr, pk->hi_l - pk->lo_l, stride(pk->lo_l, pk->hi_l), tc, 0},
-      {pk->a, z, r->a_map + pk->lo_a, pk->hi_a - pk->lo_a, stride(pk->lo_a, pk->hi_a), tc, 1},
-      {pk->b1, z, r->b_map + pk->lo_b, pk->hi_b - pk->lo_b, stride(pk->lo_b, pk->hi_b), tc, 2}};
+      {pk->l, z + r->n_in + pk->lo_l, nullptr, pk->hi_l - pk->lo_l, stride(pk->lo_l, pk->hi_l), tc, 0, pk->l_d},
+      {pk->a, z, r->a_map + pk->lo_a, pk->hi_a - pk->lo_a, stride(pk->lo_a, pk->hi_a), tc, 1, pk->a_d},
+      {pk->b1, z, r->b_map + pk->lo_b, pk->hi_b - pk->lo_b, stride(pk->lo_b, pk->hi_b), tc, 2, pk->b1_d}};
   // The main stream is the critical path (rows -> transforms -> h multiexp) and is enqueued first, so
   // the GPU is not left waiting while the host queues the other pipelines' launches.
   if (!h_external) {
@@ -482,7 +490,7 @@ static zg16_status prove_partial_impl(zg16_ctx* ctx, const zg16_pk* pk, const zg
   {
     ZG_HIP(ctx, hipStreamWaitEvent(aux, ev[E_Z], 0));
     ZG_HIP(ctx, hipEventRecord(ev[E_G2_BEGIN], aux));
-    MsmJob<Fq2> jb = {pk->b2, z, r->b_map + pk->lo_b, pk->hi_b - pk->lo_b, stride(pk->lo_b, pk->hi_b), pk->table_c_g2, 0};
+    MsmJob<Fq2> jb = {pk->b2, z, r->b_map + pk->lo_b, pk->hi_b - pk->lo_b, stride(pk->lo_b, pk->hi_b), pk->table_c_g2, 0, pk->b2_d};
     const MsmStreams ms = {aux, nullptr, nullptr, nullptr};
     ZG_TRY(msm_launch<Fq2>(ctx, ms, 2, pinned + MSM_PINNED_BYTES, &jb, 1, 1, &pend_g2));
     ZG_HIP(ctx, hipEventRecord(ev[E_G2_END], aux));
@@ -558,6 +566,15 @@ static zg16_status prove_partial_impl(zg16_ctx* ctx, const zg16_pk* pk, const zg
     ZG_TRY(enqueue());
   }
   mark("everything enqueued");
+  if (host_trace && !graphed) {  // when the GPU passes each stage boundary, on the host's clock
+    const int ids[] = {E_Z, E_SPMV, E_NTT, E_G2_END, E_Z_END, E_G1, E_END};
+    const char* names[] = {"gpu: witness staged", "gpu: rows done", "gpu: transforms done", "gpu: G2 multiexp done",
+                           "gpu: witness multiexps done", "gpu: h multiexp done", "gpu: all done"};
+    for (int k = 0; k < 7; k++) {
+      while (hipEventQuery(ev[ids[k]]) == hipErrorNotReady) __builtin_ia32_pause();
+      mark(names[k]);
+    }
+  }
   G2XYZZ qb2;
   bool early_done = false;
   if (graphed) {
@@ -586,11 +603,17 @@ static zg16_status prove_partial_impl(zg16_ctx* ctx, const zg16_pk* pk, const zg
   }
   if (tables && early) {
     early->key_terms();  // host work while the GPU is busy
-    ZG_HIP(ctx, hipEventSynchronize(ev[E_Z_END]));
+    // poll: the runtime's blocking wait wakes up to 0.3 ms late, which is half of a small circuit's proof
+    auto spin = [&](hipEvent_t e) {
+      hipError_t q;
+      while ((q = hipEventQuery(e)) == hipErrorNotReady) __builtin_ia32_pause();
+      return q;
+    };
+    ZG_HIP(ctx, spin(ev[E_Z_END]));
     ZG_TRY(msm_collect<Fq>(ctx, &pend_z, g1));
     early->with_g1(g1[1], g1[2]);
     mark("witness-query multiexps collected");
-    ZG_HIP(ctx, hipEventSynchronize(ev[E_G2_END]));
+    ZG_HIP(ctx, spin(ev[E_G2_END]));
     ZG_TRY(msm_collect<Fq2>(ctx, &pend_g2, &qb2));
     early->with_g2(qb2);
     early_done = true;
@@ -716,6 +739,8 @@ static zg16_status prove_full(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1cs*
   Assembly as;
   as.alpha1 = pk->alpha_g1; as.beta1 = pk->beta_g1; as.delta1 = pk->delta_g1;
   as.beta2 = pk->beta_g2; as.delta2 = pk->delta_g2;
+  as.delta1_table = pk->delta1_table.get();
+  as.delta2_table = pk->delta2_table.get();
   as.rc = from_mont(load_fr(r_));
   as.sc = from_mont(load_fr(s_));
   zg16_partial part;
@@ -884,12 +909,16 @@ zg16_status zg16_bases_upload(zg16_ctx* ctx, int group, const uint64_t* bases, s
   b->table_c = window_tables ? msm_table_window(n, 0) : 0;
   if (group == 1) {
     Affine<Fq>* p;
-    ZG_TRY(upload_query<Fq>(ctx, &p, bases, n, b->table_c));
+    Affine<Fq>* d;
+    ZG_TRY(upload_query<Fq>(ctx, &p, bases, n, b->table_c, &d));
     b->points = p;
+    b->direct = d;
   } else {
     Affine<Fq2>* p;
-    ZG_TRY(upload_query<Fq2>(ctx, &p, bases, n, b->table_c));
+    Affine<Fq2>* d;
+    ZG_TRY(upload_query<Fq2>(ctx, &p, bases, n, b->table_c, &d));
     b->points = p;
+    b->direct = d;
   }
   *out = b.release();
   return ZG16_OK;
@@ -899,6 +928,7 @@ void zg16_bases_free(zg16_bases* b) {
   if (!b) return;
   if (b->ctx) (void)hipSetDevice(b->ctx->device);
   (void)hipFree(b->points);
+  (void)hipFree(b->direct);
   delete b;
 }
 
@@ -915,13 +945,13 @@ zg16_status zg16_msm_resident(zg16_ctx* ctx, const zg16_bases* b, const uint64_t
   }
   const size_t stride = b->table_c ? b->n : 0;
   if (b->group == 1) {
-    MsmJob<Fq> job = {(const Affine<Fq>*)b->points, d_s, nullptr, b->n, stride, b->table_c, 0};
+    MsmJob<Fq> job = {(const Affine<Fq>*)b->points, d_s, nullptr, b->n, stride, b->table_c, 0, (const Affine<Fq>*)b->direct};
     G1XYZZ res;
     ZG_TRY(msm_g1_device(ctx, &job, 1, &res));
     const G1Affine a = to_affine(res);
     memcpy(out, &a, sizeof a);
   } else {
-    MsmJob<Fq2> job = {(const Affine<Fq2>*)b->points, d_s, nullptr, b->n, stride, b->table_c, 0};
+    MsmJob<Fq2> job = {(const Affine<Fq2>*)b->points, d_s, nullptr, b->n, stride, b->table_c, 0, (const Affine<Fq2>*)b->direct};
     G2XYZZ res;
     ZG_TRY(msm_g2_device(ctx, &job, 1, &res));
     const G2Affine a = to_affine(res);

@@ -194,6 +194,9 @@ struct MsmJob {
   size_t table_stride;
   uint32_t table_c;
   int group;  // which of the launch's results this job is summed into
+  // Optional direct table of a small query (msm_build_direct), stride table_stride: when every job of a launch
+  // brings one, the multiexp is a plain sum of looked-up multiples and `bases` is not read.
+  const Affine<F>* direct = nullptr;
 };
 // Window width / count used for key tables, and the kernel that fills windows 1..W-1 of a table whose
 // window 0 (n points, stride n) is already in place.
@@ -201,6 +204,13 @@ uint32_t msm_table_window(size_t points, int role);  // role 0: h, 1: l / a / b_
 uint32_t msm_table_windows(uint32_t c);
 template <class F>
 zg16_status msm_build_table(zg16_ctx* ctx, Affine<F>* table, size_t n, uint32_t c);
+// Direct table of a small query: every multiple d * 2^(5 w) * P_k a signed 5-bit digit can ask for, as affine
+// points in the multiexp kernels' packed form: direct[(w * 16 + (d - 1)) * n + k].  `points` are the n bases in the
+// ABI form (call it before msm_build_table rewrites them).  *out stays null when the query is larger than
+// msm_direct_max() points (or empty); the caller frees *out with hipFree.
+size_t msm_direct_max();
+template <class F>
+zg16_status msm_build_direct(zg16_ctx* ctx, const Affine<F>* points, size_t n, Affine<F>** out);
 // Blocking forms on ctx->stream: the sum of several jobs as one multiexp, one XYZZ point to `out_host`.
 zg16_status msm_g1_device(zg16_ctx* ctx, const MsmJob<Fq>* jobs, int njobs, G1XYZZ* out_host);
 zg16_status msm_g2_device(zg16_ctx* ctx, const MsmJob<Fq2>* jobs, int njobs, G2XYZZ* out_host);
@@ -214,6 +224,7 @@ static constexpr size_t MSM_PINNED_BYTES = 512 * 1024;
 struct MsmPending {
   void* pinned = nullptr;
   uint32_t nsets = 0, ngroups = 0, c = 0, shared = 0;
+  uint32_t direct = 0;  // the results are plain sums (one point per group), nothing to fold
   int acc_kernel = 0;  // KernelId whose work units (additions) are known only after the run
 };
 struct MsmStreams {

@@ -181,6 +181,59 @@ ZG_HD XYZZ<F> scalar_mul_w4(const XYZZ<F>& p, const uint32_t* k) {
   return acc;
 }
 
+// k * P for a point known in advance: t[w][j - 1] = j * 16^w * P, so the product is one addition per non-zero
+// nibble of k and no doubling (64 additions instead of ~250 doublings + 60 additions).
+template <class F>
+struct FixedBaseTable {
+  XYZZ<F> t[64][15];
+  void build(const Affine<F>& p) {
+    XYZZ<F> base = XYZZ<F>::from_affine(p);
+    for (int w = 0; w < 64; w++) {
+      t[w][0] = base;
+      for (int j = 1; j < 15; j++) {
+        t[w][j] = t[w][j - 1];
+        add_full(t[w][j], base);
+      }
+      base = t[w][14];
+      add_full(base, t[w][0]);  // 16 * 16^w * P
+    }
+  }
+  XYZZ<F> mul(const uint32_t* k) const {
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (int w = 0; w < 64; w++) {
+      const uint32_t digit = (k[w >> 3] >> (4 * (w & 7))) & 15;
+      if (digit) add_full(acc, t[w][digit - 1]);
+    }
+    return acc;
+  }
+};
+
+// k1 * p + k2 * q in one pass over both scalars, two bits of each at a time: 15 additions for the table of
+// i*p + j*q (i, j < 4), then 2 doublings and at most one addition per step (about 254 doublings + 120 additions
+// instead of twice 250 + 60).
+template <class F>
+ZG_HD XYZZ<F> double_scalar_mul(const XYZZ<F>& p, const uint32_t* k1, const XYZZ<F>& q, const uint32_t* k2) {
+  XYZZ<F> tab[4][4];
+  tab[0][0] = XYZZ<F>::inf();
+  for (int i = 0; i < 4; i++) {
+    if (i) {
+      tab[i][0] = tab[i - 1][0];
+      add_full(tab[i][0], p);
+    }
+    for (int j = 1; j < 4; j++) {
+      tab[i][j] = tab[i][j - 1];
+      add_full(tab[i][j], q);
+    }
+  }
+  XYZZ<F> acc = XYZZ<F>::inf();
+  for (int bit = 254; bit >= 0; bit -= 2) {
+    if (!acc.is_inf()) acc = dbl(dbl(acc));
+    const uint32_t d1 = (k1[bit >> 5] >> (bit & 31)) & 3, d2 = (k2[bit >> 5] >> (bit & 31)) & 3;
+    if (d1 | d2) add_full(acc, tab[d1][d2]);
+  }
+  return acc;
+}
+
 template <class F>
 ZG_HD bool on_curve(const Affine<F>& p, const F& b) {
   if (p.is_inf()) return true;

@@ -140,8 +140,9 @@ struct Cursor {
 // fill the other windows.
 template <class F>
 static zg16_status decode_query(zg16_ctx* ctx, const uint8_t* bytes, size_t lo, size_t hi, int checked, uint32_t table_c,
-                                const Fq2& curve_b, const char* name, Affine<F>** dst) {
+                                const Fq2& curve_b, const char* name, Affine<F>** dst, Affine<F>** direct) {
   *dst = nullptr;
+  *direct = nullptr;
   const size_t count = hi - lo;
   if (!count) return ZG16_OK;
   constexpr size_t PB = sizeof(Affine<F>);  // the encoding is as long as the affine point
@@ -163,6 +164,7 @@ static zg16_status decode_query(zg16_ctx* ctx, const uint8_t* bytes, size_t lo, 
   ZG_HIP(ctx, hipMemcpyAsync(&herr, err, 4, hipMemcpyDeviceToHost, ctx->stream));
   ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (herr) return fail(ctx, ZG16_ERR_MALFORMED_KEY, "%s query: %s", name, decode_text(herr));
+  if (table_c) ZG_TRY(msm_build_direct<F>(ctx, *dst, count, direct));
   return msm_build_table<F>(ctx, *dst, count, table_c);
 }
 
@@ -207,6 +209,7 @@ zg16_status zg16_pk_upload_bytes(zg16_ctx* ctx, const uint8_t* data, size_t len,
   ZG_TRY(g2(&gamma2, "gamma_g2"));
   ZG_TRY(g1(&pk->delta_g1, "delta_g1"));
   ZG_TRY(g2(&pk->delta_g2, "delta_g2"));
+  pk->build_delta_tables();
   size_t n_ic;
   if (!cur.u32be(&n_ic)) return eof();
   for (size_t i = 0; i < n_ic; i++) {
@@ -237,11 +240,11 @@ zg16_status zg16_pk_upload_bytes(zg16_ctx* ctx, const uint8_t* data, size_t len,
   pk->table_c = msm_table_window(largest, 1);
   pk->table_c_h = msm_table_window(pk->hi_h - pk->lo_h, 0);
   pk->table_c_g2 = msm_table_window(pk->hi_b - pk->lo_b, 2);
-  ZG_TRY(decode_query<Fq>(ctx, vec[0], pk->lo_h, pk->hi_h, checked, pk->table_c_h, curve_b, names[0], &pk->h));
-  ZG_TRY(decode_query<Fq>(ctx, vec[1], pk->lo_l, pk->hi_l, checked, pk->table_c, curve_b, names[1], &pk->l));
-  ZG_TRY(decode_query<Fq>(ctx, vec[2], pk->lo_a, pk->hi_a, checked, pk->table_c, curve_b, names[2], &pk->a));
-  ZG_TRY(decode_query<Fq>(ctx, vec[3], pk->lo_b, pk->hi_b, checked, pk->table_c, curve_b, names[3], &pk->b1));
-  ZG_TRY(decode_query<Fq2>(ctx, vec[4], pk->lo_b, pk->hi_b, checked, pk->table_c_g2, curve_b, names[4], &pk->b2));
+  ZG_TRY(decode_query<Fq>(ctx, vec[0], pk->lo_h, pk->hi_h, checked, pk->table_c_h, curve_b, names[0], &pk->h, &pk->h_d));
+  ZG_TRY(decode_query<Fq>(ctx, vec[1], pk->lo_l, pk->hi_l, checked, pk->table_c, curve_b, names[1], &pk->l, &pk->l_d));
+  ZG_TRY(decode_query<Fq>(ctx, vec[2], pk->lo_a, pk->hi_a, checked, pk->table_c, curve_b, names[2], &pk->a, &pk->a_d));
+  ZG_TRY(decode_query<Fq>(ctx, vec[3], pk->lo_b, pk->hi_b, checked, pk->table_c, curve_b, names[3], &pk->b1, &pk->b1_d));
+  ZG_TRY(decode_query<Fq2>(ctx, vec[4], pk->lo_b, pk->hi_b, checked, pk->table_c_g2, curve_b, names[4], &pk->b2, &pk->b2_d));
   *out = pk.release();
   return ZG16_OK;
 }

@@ -31,6 +31,8 @@
 //   7. host              : sum_b (b+1)*S_b from the folded sums; Horner over the W window sums
 //                          (per-window layout only)
 #define ZG_OUTLINE_FIELD_MUL 1
+#include <algorithm>
+
 #include "common.cuh"
 #include "msm_ops.cuh"
 
@@ -54,6 +56,7 @@ struct JobTable {
   uint32_t stride[MAX_JOBS];     // table stride (points per window); unused with per-window buckets
   uint32_t start[MAX_JOBS + 1];  // prefix offsets of the concatenated term list
   uint32_t group[MAX_JOBS];      // which result (bucket set) the job's terms are summed into
+  const Affine<F>* direct[MAX_JOBS];  // direct tables (k_direct_sum), stride `stride`
   int njobs;
 };
 
@@ -627,6 +630,121 @@ __global__ __launch_bounds__(256, kMinWaves<F>) void k_sum_range(JobTable<F> jt,
   if (lt == 0) O::store(part + ((size_t)g * gridDim.x + blockIdx.x), acc);
 }
 
+
+// ---- direct-lookup multiexp for small queries ---------------------------------------------------
+// Below ~2^14 points a bucket multiexp is ~20 dependent launches of almost no work each, and that chain is what a
+// small circuit's proof waits for.  With 288 GB of HBM such a query can instead keep EVERY multiple a digit can
+// ask for: with signed 5-bit digits, direct[(w * 16 + (|d| - 1)) * n + k] = |d| * 2^(5 w) * P_k for 52 windows --
+// 52 KiB per G1 point.  The multiexp is then a plain sum of one looked-up point per non-zero digit: one launch of
+// independent mixed additions plus the workgroup trees, one launch to add the workgroups' partial sums.
+// Digits: s' = s + sum_{w < 51} 16 * 32^w makes every window w < 51 of s' an unsigned digit u with d = u - 16 in
+// [-16, 15]; window 51 (bits 255 and up of s' < 2^256) is 0 or 1 and is taken as it is.
+static constexpr uint32_t DIRECT_C = 5, DIRECT_M = 16, DIRECT_WB = 51, DIRECT_W = 52;
+static constexpr uint32_t DIRECT_PER_THREAD = 8;  // table look-ups per logical thread of k_direct_sum
+
+struct DirectBias {
+  uint32_t v[8];  // sum_{w < 51} 16 * 32^w
+};
+
+static DirectBias direct_bias() {
+  DirectBias b = {};
+  for (uint32_t w = 0; w < DIRECT_WB; w++) {
+    const uint32_t bit = w * DIRECT_C + (DIRECT_C - 1);
+    b.v[bit >> 5] |= 1u << (bit & 31);
+  }
+  return b;
+}
+
+size_t msm_direct_max() {
+  const char* e = getenv("ZG16_DIRECT_MAX_LOG");
+  const int lg = e ? atoi(e) : 14;
+  return lg <= 0 ? 0 : (size_t)1 << (lg > 16 ? 16 : lg);
+}
+
+// One thread per (point, window): 2^(5 w) * P by doublings, then its sixteen multiples.
+template <class F>
+__global__ __launch_bounds__(256, 1) void k_build_direct(const Affine<F>* __restrict__ pts, uint32_t n,
+                                                         Affine<F>* __restrict__ out) {
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * DIRECT_W) return;
+  const uint32_t w = idx / n, k = idx - w * n;
+  const Affine<F> p = pts[k];
+  Affine<F>* dst = out + ((size_t)w * DIRECT_M * n + k);
+  if (p.is_inf()) {  // an identity base stays one in every multiple (and is reported when a digit asks for it)
+    for (uint32_t j = 0; j < DIRECT_M; j++) dst[(size_t)j * n] = p;
+    return;
+  }
+  XYZZ<F> acc = XYZZ<F>::from_affine(p);
+  for (uint32_t d = 0; d < w * DIRECT_C; d++) acc = dbl(acc);
+  const Affine<F> base = to_affine(acc);
+  dst[0] = MsmOps<F>::to_internal(base);
+  for (uint32_t j = 1; j < DIRECT_M; j++) {
+    add_mixed(acc, base);
+    dst[(size_t)j * n] = MsmOps<F>::to_internal(to_affine(acc));
+  }
+}
+
+template <class F>
+zg16_status msm_build_direct(zg16_ctx* ctx, const Affine<F>* points, size_t n, Affine<F>** out) {
+  *out = nullptr;
+  if (!n || n > msm_direct_max()) return ZG16_OK;
+  const size_t entries = n * DIRECT_W * DIRECT_M;
+  ZG_HIP(ctx, hipMalloc((void**)out, entries * sizeof(Affine<F>)));
+  k_build_direct<F><<<(unsigned)((n * DIRECT_W + 255) / 256), 256, 0, ctx->stream>>>(points, (uint32_t)n, *out);
+  ZG_HIP(ctx, hipGetLastError());
+  ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ZG16_OK;
+}
+template zg16_status msm_build_direct<Fq>(zg16_ctx*, const Affine<Fq>*, size_t, Affine<Fq>**);
+template zg16_status msm_build_direct<Fq2>(zg16_ctx*, const Affine<Fq2>*, size_t, Affine<Fq2>**);
+
+// Job blockIdx.y: every logical thread adds the looked-up multiples of a contiguous share of the job's
+// (window, term) pairs, the workgroup tree-adds, one partial per workgroup at part[job * gridDim.x + blockIdx.x].
+template <class F>
+__global__ __launch_bounds__(256, kMinWaves<F>) void k_direct_sum(JobTable<F> jt, DirectBias bias,
+                                                                    typename MsmOps<F>::PtMem* __restrict__ part,
+                                                                    uint32_t* __restrict__ err_flag) {
+  using O = MsmOps<F>;
+  __shared__ typename O::Pt sh[128];
+  const int j = blockIdx.y;
+  const uint32_t n = jt.start[j + 1] - jt.start[j];
+  const uint32_t lt = threadIdx.x / O::LP, nlt = 256 / O::LP;
+  const uint32_t total = n * DIRECT_W;
+  const uint32_t nthreads = gridDim.x * nlt, t = blockIdx.x * nlt + lt;
+  const uint32_t per = (total + nthreads - 1) / nthreads;
+  const uint32_t a = (uint64_t)t * per < total ? t * per : total;
+  const uint32_t b = total - a > per ? a + per : total;
+  typename O::Pt acc = O::inf();
+  uint32_t w = n ? a / n : 0, k = n ? a - w * n : 0;
+  for (uint32_t e = a; e < b; e++) {
+    const Fr s = from_mont(load_scalar(jt, jt.start[j] + k, j));
+    uint32_t sp[8];
+    uint64_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      carry += (uint64_t)s.v[i] + bias.v[i];
+      sp[i] = (uint32_t)carry;
+      carry >>= 32;
+    }
+    const uint32_t u = extract_bits(sp, w * DIRECT_C, DIRECT_C);
+    const int d = w < DIRECT_WB ? (int)u - (int)DIRECT_M : (int)u;
+    if (d != 0) {
+      const uint32_t mag = (uint32_t)(d < 0 ? -d : d) - 1;
+      typename O::Aff p;
+      if (O::load_base(jt.direct[j] + ((size_t)(w * DIRECT_M + mag) * jt.stride[j] + k), d < 0, &p))
+        O::madd(acc, p);
+      else
+        *err_flag = 1;  // identity base consumed by a non-zero scalar
+    }
+    if (++k == n) {
+      k = 0;
+      w++;
+    }
+  }
+  block_sum<F>(acc, sh);
+  if (lt == 0) O::store(part + ((size_t)j * gridDim.x + blockIdx.x), acc);
+}
+
 // table[w*stride + i] = 2^(c*w) * table[i] for w in 1..W-1, every window in the internal packed form
 // (window 0 arrives in the ABI form and is rewritten).  W = 1 just converts the points.
 template <class F>
@@ -724,7 +842,7 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
   JobTable<F> jt = {};
   size_t n = 0;
   int nj = 0;
-  bool all_tables = true;
+  bool all_tables = true, all_direct = true;  // direct: every job has a direct table and is its own group
   uint32_t table_c = 0;
   for (int j = 0; j < njobs; j++) {
     if (!jobs[j].n) continue;
@@ -735,6 +853,8 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
     jt.stride[nj] = (uint32_t)jobs[j].table_stride;
     jt.start[nj] = (uint32_t)n;
     jt.group[nj] = (uint32_t)jobs[j].group;
+    jt.direct[nj] = jobs[j].direct;
+    if (!jobs[j].direct || jobs[j].group != nj) all_direct = false;
     if (!jobs[j].table_stride || (table_c && jobs[j].table_c != table_c)) all_tables = false;
     table_c = jobs[j].table_c;
     n += jobs[j].n;
@@ -745,9 +865,39 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
   pend->pinned = pinned;
   pend->ngroups = (uint32_t)ngroups;
   pend->nsets = 0;
+  pend->direct = 0;
   if (n == 0) return ZG16_OK;
   if (n >= 0x7fffffffu) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "multiexp of %zu terms exceeds 2^31", n);
   if (!all_tables && ngroups != 1) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "grouped multiexp needs window tables");
+  if (all_direct && nj == ngroups) {
+    // small queries with direct tables: two launches (see k_direct_sum)
+    using PtMem = typename MsmOps<F>::PtMem;
+    size_t largest = 0;
+    for (int j = 0; j < nj; j++) largest = std::max<size_t>(largest, jt.start[j + 1] - jt.start[j]);
+    const size_t per_block = (size_t)(256 / MsmOps<F>::LP) * DIRECT_PER_THREAD;
+    uint32_t blocks = (uint32_t)((largest * DIRECT_W + per_block - 1) / per_block);
+    if (blocks > 1024) blocks = 1024;
+    auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_part = 256, o_out = o_part + align((size_t)nj * blocks * sizeof(PtMem));
+    char* base;
+    ZG_TRY(scratch_get(ctx, scratch_slot, o_out + align((size_t)nj * sizeof(XYZZ<F>)), (void**)&base));
+    uint32_t* err = (uint32_t*)base;
+    PtMem* part = (PtMem*)(base + o_part);
+    XYZZ<F>* wstd = (XYZZ<F>*)(base + o_out);
+    ZG_HIP(ctx, hipMemsetAsync(base, 0, 256, st));
+    {
+      KernelTimer kt(ctx, sizeof(F) > sizeof(Fq) ? K_MSM_ONES_G2 : K_MSM_ONES_G1, (double)n, st);
+      k_direct_sum<F><<<dim3(blocks, nj), 256, 0, st>>>(jt, direct_bias(), part, err);
+      k_sum_partials<F><<<nj, 256, 0, st>>>(part, blocks, wstd);
+    }
+    ZG_HIP(ctx, hipGetLastError());
+    ZG_HIP(ctx, hipMemcpyAsync(pinned, err, 8, hipMemcpyDeviceToHost, st));
+    ZG_HIP(ctx, hipMemcpyAsync((char*)pinned + PINNED_POINTS, wstd, (size_t)nj * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
+    pend->nsets = 1;
+    pend->direct = 1;
+    pend->acc_kernel = sizeof(F) > sizeof(Fq) ? K_MSM_ACC0_G2 : K_MSM_ACC0_G1;
+    return ZG16_OK;
+  }
 
   MsmShape sh;
   sh.n = (uint32_t)n;
@@ -949,6 +1099,11 @@ zg16_status msm_collect(zg16_ctx* ctx, const MsmPending* pend, XYZZ<F>* out) {
   if (!pend->nsets) return ZG16_OK;  // no terms
   const uint32_t* head = (const uint32_t*)pend->pinned;
   if (head[0]) return fail(ctx, ZG16_ERR_UNEXPECTED_IDENTITY, "multiexp consumed a base at infinity");
+  if (pend->direct) {
+    const XYZZ<F>* sums = (const XYZZ<F>*)((const char*)pend->pinned + PINNED_POINTS);
+    for (uint32_t g = 0; g < pend->ngroups; g++) out[g] = sums[g];
+    return ZG16_OK;
+  }
   if (ctx->profile) ctx->kstat[pend->acc_kernel].units += head[1];
   const XYZZ<F>* hw = (const XYZZ<F>*)((const char*)pend->pinned + PINNED_POINTS);
   const FoldShape fold(pend->c - 1);

@@ -1,6 +1,8 @@
 // Device-resident constraint matrices and proving key (internal definitions of the opaque
 // handles declared in include/zinc_groth16.h).
 #pragma once
+#include <memory>
+
 #include "common.cuh"
 
 namespace zg {
@@ -43,6 +45,9 @@ struct zg16_pk {
   size_t lo_h = 0, hi_h = 0, lo_l = 0, hi_l = 0, lo_a = 0, hi_a = 0, lo_b = 0, hi_b = 0;
   zg::G1Affine *h = nullptr, *l = nullptr, *a = nullptr, *b1 = nullptr;
   zg::G2Affine* b2 = nullptr;
+  // Direct tables (msm_build_direct) of the queries that are small enough, else null; same point ranges.
+  zg::G1Affine *h_d = nullptr, *l_d = nullptr, *a_d = nullptr, *b1_d = nullptr;
+  zg::G2Affine* b2_d = nullptr;
   // When table_c != 0 each query array holds msm_table_windows(c) windows of its shard, c being the
   // query's own width below: q[w * (hi - lo) + k] = 2^(c * w) * P_(lo + k).
   uint32_t table_c = 0;       // l, a, b_g1 (one launch, one width)
@@ -50,6 +55,17 @@ struct zg16_pk {
   uint32_t table_c_g2 = 0;    // b_g2
   zg::G1Affine alpha_g1, beta_g1, delta_g1;
   zg::G2Affine beta_g2, delta_g2;
+  // r * delta_g1 and s * delta_g2 open every proof's assembly on the host; delta is fixed per key, so the key
+  // keeps fixed-base tables of both (host memory, built at upload by build_delta_tables).
+  std::unique_ptr<zg::FixedBaseTable<zg::Fq>> delta1_table;
+  std::unique_ptr<zg::FixedBaseTable<zg::Fq2>> delta2_table;
+  void build_delta_tables() {
+    if (delta_g1.is_inf() || delta_g2.is_inf()) return;  // such a key is rejected when it is used
+    delta1_table.reset(new zg::FixedBaseTable<zg::Fq>());
+    delta1_table->build(delta_g1);
+    delta2_table.reset(new zg::FixedBaseTable<zg::Fq2>());
+    delta2_table->build(delta_g2);
+  }
 };
 
 // A base set resident in HBM (zg16_bases_upload): `n` points, optionally as a window table.
@@ -59,4 +75,5 @@ struct zg16_bases {
   size_t n = 0;
   uint32_t table_c = 0;
   void* points = nullptr;  // Affine<Fq> or Affine<Fq2>, in the multiexp kernels' packed form
+  void* direct = nullptr;  // direct table (msm_build_direct) when the set is small and has window tables
 };
