@@ -289,6 +289,47 @@ def test_msm_resident_bases(gpu_ctx, group, n, tables):
     res.free()
 
 
+@pytest.mark.parametrize("group,n", [("g1", 5000), ("g2", 700)])
+def test_msm_direct_tables_vs_buckets_and_oracle(gpu_ctx, group, n):
+    """A small resident base set is summed through its direct table (every digit multiple looked up, no
+    buckets); the same set uploaded with direct tables switched off goes through the bucket pipeline.  Both equal
+    the CPU oracle on scalars chosen to hit the digit recoding's corners: 0, 1, 2, 15, 16, 17, 31, 32, r-1, r-2,
+    (r-1)/2, all-ones, every window 15 / 16 / 17, single high bits, and an identity base under a zero scalar."""
+    from oracle import cpu_binding as cb
+    from zinc_amd import workload
+    from zinc_amd.groth16 import ResidentBases
+    rng = np.random.default_rng(n)
+    g1gen, g2gen = workload._generators()
+    ks = rand_fr(rng, n)
+    bases = workload.fixed_base_g1(gpu_ctx, g1gen, ks) if group == "g1" else workload.fixed_base_g2(gpu_ctx, g2gen, ks)
+    every = lambda d: sum(d << (5 * w) for w in range(50))
+    edge = [0, 1, 2, 15, 16, 17, 31, 32, 33, R_MOD - 1, R_MOD - 2, (R_MOD - 1) // 2, (1 << 253) - 1, every(15), every(16),
+            every(17), every(31), 1 << 250, 1 << 253, (1 << 253) + (1 << 252), 16 << 250, 15 << 250]
+    sc = rand_fr(rng, n)
+    sc[: len(edge)] = ints_to_mont(edge, R_MOD)
+    sc[100:140:2] = ints_to_mont([1], R_MOD)[0]
+    bases[0] = 0          # the point at infinity, under a zero scalar: consumed by nobody
+    st, want = cb.multiexp(group, bases, sc, None, threads=8)
+    assert st == 0
+    gid = 1 if group == "g1" else 2
+    direct = ResidentBases(gpu_ctx, gid, bases, window_tables=True)
+    os.environ["ZG16_DIRECT_MAX_LOG"] = "0"
+    try:
+        buckets = ResidentBases(gpu_ctx, gid, bases, window_tables=True)
+    finally:
+        del os.environ["ZG16_DIRECT_MAX_LOG"]
+    assert np.array_equal(direct.msm(sc), want)
+    assert np.array_equal(buckets.msm(sc), want)
+    # an identity base under a non-zero scalar is bellman's UnexpectedIdentity on both paths
+    sc[0] = ints_to_mont([5], R_MOD)[0]
+    for res in (direct, buckets):
+        with pytest.raises(SynthesisError) as e:
+            res.msm(sc)
+        assert e.value.status_name == "UnexpectedIdentity"
+    direct.free()
+    buckets.free()
+
+
 def test_msm_full_size_linearity(gpu_ctx):
     """2^20 points: msm(s) + msm(t) == msm(s + t) and msm(k*s) == k*msm(s), via 3-term multiexps."""
     from zinc_amd import workload
