@@ -379,10 +379,15 @@ __global__ __launch_bounds__(256) void k_scan_fixup(uint32_t* __restrict__ off, 
   }
 }
 
-// Entries per lane of k_accumulate: the launch has a fixed number of lanes (sized to fill the GPU
-// once) and the sorted entries are dealt out evenly, so the chunk length follows the entry count.
-ZG_D uint32_t chunk_len(uint32_t entries, uint32_t lanes) {
-  const uint32_t k = (entries + lanes - 1) / lanes;
+// Entries per lane of k_accumulate: the launch has a fixed number of lanes (sized to fill the GPU once) and the
+// sorted entries are dealt out evenly, so the chunk length follows the entry count -- but never so short that an
+// average bucket is cut into more than ~24 pieces (a sweep of 8 .. 28 was flat within noise above 12): mid-sized multiexps (2^15 .. 2^17 dense terms) have few,
+// large buckets, and with 8-entry chunks every one of them went down the one-workgroup-per-bucket path
+// (k_heavy: 0.49 ms of a 1.7 ms proof at 2^16 rows) instead of k_combine's.
+ZG_D uint32_t chunk_len(uint32_t entries, uint32_t lanes, uint32_t nb) {
+  uint32_t k = (entries + lanes - 1) / lanes;
+  const uint32_t per_bucket = entries / nb / 24;
+  if (k < per_bucket) k = per_bucket;
   return k < ACC_KMIN ? ACC_KMIN : k;
 }
 
@@ -409,7 +414,7 @@ __global__ __launch_bounds__(256, kMinWaves<F>) void k_accumulate(JobTable<F> jt
   using O = MsmOps<F>;
   const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) / O::LP;
   const uint32_t nslots = off[nb];  // digit entries; the unit-scalar entries behind them go to k_sum_range
-  const uint32_t K = chunk_len(nslots, lanes);
+  const uint32_t K = chunk_len(nslots, lanes, nb);
   const uint64_t lo64 = (uint64_t)t * K;
   if (lo64 >= nslots) return;
   const uint32_t lo = (uint32_t)lo64;
@@ -459,7 +464,7 @@ __global__ __launch_bounds__(256, kMinWaves<F>) void k_combine(uint32_t nb, uint
   using O = MsmOps<F>;
   const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) / O::LP;
   const uint32_t b = t / L, sub = t % L;
-  const uint32_t K = chunk_len(off[nb], lanes);
+  const uint32_t K = chunk_len(off[nb], lanes, nb);
   uint32_t s = 0, pieces = 0;  // pieces == 0: nothing to add here
   if (b < nb) {
     s = off[b];
@@ -525,7 +530,7 @@ __global__ __launch_bounds__(256, kMinWaves<F>) void k_heavy(const uint32_t* __r
   using O = MsmOps<F>;
   __shared__ typename O::Pt sh[128];
   const uint32_t n = *heavy_count;
-  const uint32_t K = chunk_len(off[nb], lanes);
+  const uint32_t K = chunk_len(off[nb], lanes, nb);
   const uint32_t lt = threadIdx.x / O::LP, nlt = 256 / O::LP;
   for (uint32_t h = blockIdx.x; h < n; h += gridDim.x) {
     const uint32_t b = heavy_list[h];
