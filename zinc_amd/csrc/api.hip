@@ -770,7 +770,7 @@ zg16_status zg16_prove_from_evals(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r
 static const char* const kKernelNames[K_COUNT] = {
     "k_spmv_short+long", "k_ntt_pass", "k_scale_powers", "k_mul_sub_scale", "k_sort_*+k_fine_*+k_scan_*", "k_scan",
     "k_accumulate<G1>", "k_accumulate<G2>", "k_combine+k_heavy<G1>", "k_combine+k_heavy<G2>",
-    "k_split_sums<G1>", "k_split_sums<G2>", "k_sum_range<G1>", "k_sum_range<G2>"};
+    "k_split_sums<G1>", "k_split_sums<G2>", "k_sum_range|k_direct_sum<G1>", "k_sum_range|k_direct_sum<G2>"};
 
 zg16_status zg16_graph_mode(zg16_ctx* ctx, int mode) {
   if (!ctx) return ZG16_ERR_INVALID_ARGUMENT;
