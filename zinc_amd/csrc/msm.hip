@@ -156,7 +156,7 @@ ZG_D void term_digits(const JobTable<F>& jt, const MsmShape& sh, uint32_t i, FD 
 
 template <class F>
 __global__ __launch_bounds__(256) void k_sort_count(JobTable<F> jt, MsmShape sh, SortShape ss,
-                                                    uint32_t* __restrict__ chist) {
+                                                    uint32_t* __restrict__ chist, uint32_t* __restrict__ wg_hist) {
   __shared__ uint32_t lh[SORT_MAX_COARSE + MAX_JOBS];
   const uint32_t tid = threadIdx.x, nbins = ss.ncoarse + sh.G;
   for (uint32_t j = tid; j < nbins; j += 256) lh[j] = 0;
@@ -169,8 +169,11 @@ __global__ __launch_bounds__(256) void k_sort_count(JobTable<F> jt, MsmShape sh,
                   [&](uint32_t g) { atomicAdd(&lh[ss.ncoarse + g], 1u); });
   }
   __syncthreads();
-  for (uint32_t j = tid; j < nbins; j += 256)
+  // bin-major, so that one exclusive scan over the whole array gives every (bin, workgroup) its run's start
+  for (uint32_t j = tid; j < nbins; j += 256) {
+    wg_hist[(size_t)j * gridDim.x + blockIdx.x] = lh[j];
     if (lh[j]) atomicAdd(&chist[j], lh[j]);
+  }
 }
 
 // One workgroup: coff = exclusive scan of chist[0..nbins) (coff[nbins] = total), ccursor = copy of it,
@@ -199,27 +202,17 @@ __global__ __launch_bounds__(1024) void k_scan_coarse(const uint32_t* __restrict
 
 template <class F>
 __global__ __launch_bounds__(256) void k_sort_scatter(JobTable<F> jt, MsmShape sh, SortShape ss,
-                                                      uint32_t* __restrict__ ccursor, uint2* __restrict__ rec_coarse,
+                                                      const uint32_t* __restrict__ wg_off, uint2* __restrict__ rec_coarse,
                                                       uint2* __restrict__ rec_final) {
-  __shared__ uint32_t lh[SORT_MAX_COARSE + MAX_JOBS];     // count, then cursor inside the reserved run
-  __shared__ uint32_t lbase[SORT_MAX_COARSE + MAX_JOBS];  // start of the run reserved in each bin
+  __shared__ uint32_t lh[SORT_MAX_COARSE + MAX_JOBS];     // cursor inside this workgroup's run of each bin
+  __shared__ uint32_t lbase[SORT_MAX_COARSE + MAX_JOBS];  // start of that run (scanned k_sort_count histogram)
   const uint32_t tid = threadIdx.x, nbins = ss.ncoarse + sh.G;
-  for (uint32_t j = tid; j < nbins; j += 256) lh[j] = 0;
+  for (uint32_t j = tid; j < nbins; j += 256) {
+    lh[j] = 0;
+    lbase[j] = wg_off[(size_t)j * gridDim.x + blockIdx.x];
+  }
   __syncthreads();
   const uint32_t tile = blockIdx.x * (256 * SORT_TERMS);
-  for (uint32_t k = 0; k < SORT_TERMS; k++) {
-    const uint32_t i = tile + k * 256 + tid;
-    if (i < sh.n)
-      term_digits(jt, sh, i, [&](uint32_t b, uint32_t, uint32_t) { atomicAdd(&lh[b >> ss.shift], 1u); },
-                  [&](uint32_t g) { atomicAdd(&lh[ss.ncoarse + g], 1u); });
-  }
-  __syncthreads();
-  for (uint32_t j = tid; j < nbins; j += 256) {
-    const uint32_t cnt = lh[j];
-    if (cnt) lbase[j] = atomicAdd(&ccursor[j], cnt);
-    lh[j] = 0;
-  }
-  __syncthreads();
   for (uint32_t k = 0; k < SORT_TERMS; k++) {
     const uint32_t i = tile + k * 256 + tid;
     if (i < sh.n)
@@ -313,8 +306,9 @@ __global__ __launch_bounds__(256) void k_fine_scatter(const uint2* __restrict__ 
 // launches: per-workgroup scans of 4096 counters, a scan of the workgroup totals, a fix-up.
 static constexpr uint32_t SCAN_TILE = 4096;
 
-__global__ __launch_bounds__(256) void k_scan_local(const uint32_t* __restrict__ hist, uint32_t count,
-                                                    uint32_t* __restrict__ off, uint32_t* __restrict__ tile_sum) {
+// (hist and off may be the same array: a lane reads its sixteen counters before it writes them)
+__global__ __launch_bounds__(256) void k_scan_local(const uint32_t* hist, uint32_t count, uint32_t* off,
+                                                    uint32_t* __restrict__ tile_sum) {
   __shared__ uint32_t part[256];
   const uint32_t tid = threadIdx.x;
   const uint32_t base = blockIdx.x * SCAN_TILE + tid * 16;
@@ -366,9 +360,9 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(uint32_t* __restrict__ tile
   if (tid == 1023) tile_sum[ntiles] = part[1023];
 }
 
-__global__ __launch_bounds__(256) void k_scan_fixup(uint32_t* __restrict__ off, uint32_t* __restrict__ cursor,
-                                                    uint32_t count, const uint32_t* __restrict__ tile_sum,
-                                                    uint32_t ntiles) {
+// (cursor may be the same array as off)
+__global__ __launch_bounds__(256) void k_scan_fixup(uint32_t* off, uint32_t* cursor, uint32_t count,
+                                                    const uint32_t* __restrict__ tile_sum, uint32_t ntiles) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < count) {
     const uint32_t v = off[i] + tile_sum[i / SCAN_TILE];
@@ -962,6 +956,13 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
   uint32_t ones_blocks = (uint32_t)((n + ones_div - 1) / ones_div);
   if (ones_blocks > 1024) ones_blocks = 1024;
   const size_t o_tiles = o;  o += align((size_t)(ntiles + 1) * 4);
+  // per-workgroup coarse histograms of the sort (bin-major) and the tile sums of their scan
+  const unsigned sgrid = (unsigned)((n + 256 * SORT_TERMS - 1) / (256 * SORT_TERMS));
+  const size_t n_wgh = (size_t)nbins * sgrid;
+  if (n_wgh >= 0xffffffffull) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "multiexp too large for the sort's histogram scan");
+  const uint32_t wg_tiles = (uint32_t)((n_wgh + SCAN_TILE - 1) / SCAN_TILE);
+  const size_t o_wgh = o;    o += align((n_wgh + 1) * 4);
+  const size_t o_wgt = o;    o += align((size_t)(wg_tiles + 1) * 4);
   const size_t o_part = o;   o += align((size_t)sh.G * ones_blocks * sizeof(PtMem));
   char* base;
   ZG_TRY(scratch_get(ctx, scratch_slot, o, (void**)&base));
@@ -979,17 +980,22 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
   PtMem* mid = (PtMem*)(base + o_mid);
   XYZZ<F>* wstd = (XYZZ<F>*)(base + o_wstd);
   uint32_t* tiles = (uint32_t*)(base + o_tiles);
+  uint32_t* wg_hist = (uint32_t*)(base + o_wgh);
+  uint32_t* wg_tiles_sum = (uint32_t*)(base + o_wgt);
   PtMem* ones_part = (PtMem*)(base + o_part);
 
   ZG_HIP(ctx, hipMemsetAsync(base, 0, o_zero_end, st));  // every counter and flag
   ZG_HIP(ctx, hipMemsetAsync(bsum, 0, (size_t)sh.nb * sizeof(PtMem), st));
   {
     KernelTimer kt(ctx, K_MSM_DIGITS, (double)n, st);
-    const unsigned sgrid = (unsigned)((n + 256 * SORT_TERMS - 1) / (256 * SORT_TERMS));
     const unsigned fgrid = (unsigned)((max_entries + FINE_TILE - 1) / FINE_TILE);
-    k_sort_count<F><<<sgrid, 256, 0, st>>>(jt, sh, ss, chist);
+    k_sort_count<F><<<sgrid, 256, 0, st>>>(jt, sh, ss, chist, wg_hist);
     k_scan_coarse<<<1, 1024, 0, st>>>(chist, ss.ncoarse, sh.G, coff, ccursor, hist, sh.nb);
-    k_sort_scatter<F><<<sgrid, 256, 0, st>>>(jt, sh, ss, ccursor, rec0, rec);
+    // exclusive scan of the (bin, workgroup) histogram, in place: every workgroup's run start in every bin
+    k_scan_local<<<wg_tiles, 256, 0, st>>>(wg_hist, (uint32_t)n_wgh, wg_hist, wg_tiles_sum);
+    k_scan_tiles<<<1, 1024, 0, st>>>(wg_tiles_sum, wg_tiles);
+    k_scan_fixup<<<(unsigned)((n_wgh + 1 + 255) / 256), 256, 0, st>>>(wg_hist, wg_hist, (uint32_t)n_wgh, wg_tiles_sum, wg_tiles);
+    k_sort_scatter<F><<<sgrid, 256, 0, st>>>(jt, sh, ss, wg_hist, rec0, rec);
     k_fine_count<<<fgrid, 256, 0, st>>>(rec0, coff, ss, hist);
     k_scan_local<<<ntiles, 256, 0, st>>>(hist, ncount, off, tiles);
     k_scan_tiles<<<1, 1024, 0, st>>>(tiles, ntiles);
