@@ -108,8 +108,9 @@ ZG_D uint32_t extract_bits(const uint32_t* v, uint32_t lo, uint32_t c) {
 //   k_sort_count    terms -> digits -> LDS histogram of coarse bins (bucket >> shift, at most
 //                   SORT_MAX_COARSE of them) -> one global add per non-empty bin per workgroup
 //   k_scan_coarse   exclusive scan of the coarse bins (one workgroup)
-//   k_sort_scatter  same digits again; the workgroup reserves a run in every coarse bin with one
-//                   fetch-add and writes its entries there.  Unit scalars go straight to their final
+//   k_sort_scatter  same digits again; a scan of the per-workgroup histograms k_sort_count left behind gives
+//                   the workgroup its run in every coarse bin, and it writes its entries there (ranks by LDS
+//                   atomics, no global atomic at all).  Unit scalars go straight to their final
 //                   place behind all digit entries.
 //   k_fine_count / k_fine_scatter   tiles of the coarse-sorted entries span a few coarse bins, so
 //                   their buckets are counted / ranked in LDS and again cost one global atomic per
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(256) void k_sort_count(JobTable<F> jt, MsmShape sh,
   }
 }
 
-// One workgroup: coff = exclusive scan of chist[0..nbins) (coff[nbins] = total), ccursor = copy of it,
+// One workgroup: coff = exclusive scan of chist[0..nbins) (coff[nbins] = total), ccursor = copy of it (unused now),
 // and hist[nb + g] = number of unit scalars of group g so that the bucket scan places them too.
 __global__ __launch_bounds__(1024) void k_scan_coarse(const uint32_t* __restrict__ chist, uint32_t ncoarse, uint32_t G,
                                                       uint32_t* __restrict__ coff, uint32_t* __restrict__ ccursor,
