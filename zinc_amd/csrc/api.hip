@@ -563,7 +563,13 @@ static zg16_status prove_partial_impl(zg16_ctx* ctx, const zg16_pk* pk, const zg
     ctx->graph_replays++;
   } else {
     if (pg) pg->seen++;
-    ZG_TRY(enqueue());
+    const zg16_status es = enqueue();
+    if (es != ZG16_OK) {
+      // part of the proof may already be queued on several streams: let it drain before the caller can reuse
+      // (or free) anything it touches
+      (void)hipDeviceSynchronize();
+      return es;
+    }
   }
   mark("everything enqueued");
   if (host_trace && !graphed) {  // when the GPU passes each stage boundary, on the host's clock
