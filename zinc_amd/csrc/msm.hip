@@ -874,7 +874,10 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
     using PtMem = typename MsmOps<F>::PtMem;
     size_t largest = 0;
     for (int j = 0; j < nj; j++) largest = std::max<size_t>(largest, jt.start[j + 1] - jt.start[j]);
-    const size_t per_block = (size_t)(256 / MsmOps<F>::LP) * DIRECT_PER_THREAD;
+    // the launch is a latency chain (look-ups per thread, then the workgroup tree): tiny queries take half the
+    // look-ups per thread
+    const size_t per_thread = largest * DIRECT_W < ((size_t)1 << 17) ? DIRECT_PER_THREAD / 2 : DIRECT_PER_THREAD;
+    const size_t per_block = (size_t)(256 / MsmOps<F>::LP) * per_thread;
     uint32_t blocks = (uint32_t)((largest * DIRECT_W + per_block - 1) / per_block);
     if (blocks > 1024) blocks = 1024;
     auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
