@@ -275,9 +275,9 @@ zg16_status zg16_selftest_group(zg16_ctx* ctx, int group, int op, const uint64_t
  * With profiling enabled every kernel launch is bracketed by two HIP events on the context's
  * stream; totals accumulate per kernel kind until reset.  `units` is the algorithmic work the
  * launches covered: bytes for the SpMV / NTT kernels, terms for k_digits, additions for the
- * k_accumulate kernels, buckets for k_scan / k_split_sums.  on = 2 times only the kernels that
- * dominate (SpMV, NTT pass, k_accumulate), which keeps the timed run within a percent of an
- * untimed one; the events of on = 1 cost about 3 % of a 2^20-row prove. */
+ * k_accumulate kernels, buckets for k_scan / k_split_sums.  on = 2 times only the kernel that
+ * dominates (k_accumulate, three launches per proof), which keeps the timed run within a percent or two of an
+ * untimed one; the events of on = 1 cost about 5 % of a 2^20-row prove. */
 zg16_status zg16_profile_enable(zg16_ctx* ctx, int on);
 /* on = 1: a prove issues every stage on one stream, so that per-kernel timings are free of the
  * contention between the overlapped pipelines (slower overall); 0: overlapped (the default);

@@ -135,7 +135,7 @@ struct KernelTimer {
     ctx->pending.push_back(p);
   }
   static bool roofline_kind(int id) {
-    return id == K_SPMV || id == K_NTT_PASS || id == K_MSM_ACC0_G1 || id == K_MSM_ACC0_G2;
+    return id == K_MSM_ACC0_G1 || id == K_MSM_ACC0_G2;  // the dominant kernel (three launches per proof)
   }
   hipEvent_t grab() {
     if (!ctx->event_pool.empty()) {
