@@ -123,8 +123,9 @@ zg16_status zg16_pk_upload_bytes(zg16_ctx* ctx, const uint8_t* data, size_t len,
 zg16_status zg16_pk_vk_view(const zg16_pk* pk, zg16_pk_view* out);
 
 /* ---- constraint matrices ------------------------------------------------------------------ */
-/* Upload A, B, C once per circuit; the structure does not depend on the witness.  Computes the
- * A/B density maps (which variables own a base in the a / b queries) on the device. */
+/* Upload A, B, C once per circuit; the structure does not depend on the witness.  Also derives the
+ * A/B density maps (which variables own a base in the a / b queries) from the column indices, the
+ * job bellman's DensityTracker does while zinc-vm synthesizes. */
 zg16_status zg16_r1cs_upload(zg16_ctx* ctx, const zg16_r1cs_view* view, zg16_r1cs** out);
 void        zg16_r1cs_free(zg16_r1cs* r1cs);
 /* popcounts of the density maps: a_aux, b_input, b_aux (any pointer may be NULL). */

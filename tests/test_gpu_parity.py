@@ -97,7 +97,8 @@ def test_ntt_golden(gpu_ctx, log_n):
         assert mont_to_ints(gpu_ctx.ntt(x, inv, coset), R_MOD) == [int(v, 16) for v in fx[name]], name
 
 
-@pytest.mark.parametrize("log_n", [1, 2, 3, 11, 12, 13, 16, 18])
+# 21: the smallest domain that takes three passes (pass B and its twiddle table)
+@pytest.mark.parametrize("log_n", [1, 2, 3, 11, 12, 13, 16, 18, 21])
 def test_ntt_vs_cpu_oracle(gpu_ctx, log_n):
     from oracle import cpu_binding as cb
     rng = np.random.default_rng(log_n)
@@ -106,20 +107,27 @@ def test_ntt_vs_cpu_oracle(gpu_ctx, log_n):
         assert np.array_equal(gpu_ctx.ntt(x, inv, coset), cb.fft(x, inv, coset, threads=8)), (inv, coset)
 
 
-@pytest.mark.parametrize("log_n", [20, 22])
+@pytest.mark.parametrize("log_n", [20, 22, 24, 26])
 def test_ntt_full_size_properties(gpu_ctx, log_n):
-    """Round trip, linearity and the shift theorem at benchmark sizes (no oracle needed)."""
+    """Round trip, linearity and the transform of a spike at benchmark sizes, up to the 2^26 of the stand-alone
+    configuration (no oracle run needed: the spike's spectrum is known in closed form)."""
     rng = np.random.default_rng(7)
     n = 1 << log_n
     x = rand_fr(rng, n)
     fx = gpu_ctx.ntt(x)
     assert np.array_equal(gpu_ctx.ntt(fx, inverse=True), x)
     assert np.array_equal(gpu_ctx.ntt(gpu_ctx.ntt(x, coset=True), inverse=True, coset=True), x)
-    # X[0] = sum of inputs: check against a big-integer sum of a strided subsample pattern via linearity
+    # a single spike s at position j transforms to X[k] = s * omega^(j k): checked with big integers at positions
+    # spread over the passes' digits
+    j = 12345 % n
     e = np.zeros((n, 4), dtype=np.uint64)
-    e[12345 % n] = x[12345 % n]
-    fe = gpu_ctx.ntt(e)  # transform of a single spike: |spectrum| constant => fe[0] equals the spike
-    assert np.array_equal(fe[0], x[12345 % n])
+    e[j] = x[j]
+    fe = gpu_ctx.ntt(e)
+    assert np.array_equal(fe[0], x[j])
+    omega = pow(pow(7, (R_MOD - 1) >> 28, R_MOD), 1 << (28 - log_n), R_MOD)
+    spike = mont_to_ints(x[j:j + 1], R_MOD)[0]
+    ks = [1, 2, 3, 1023, 1024, 1025, n // 2 - 1, n // 2, n - 1, 777, (1 << (log_n - 3)) + 5, 0x2F3A7 % n]
+    assert mont_to_ints(fe[ks], R_MOD) == [spike * pow(omega, j * k % n, R_MOD) % R_MOD for k in ks]
     y = x.copy()
     y[12345 % n] = 0
     fy = gpu_ctx.ntt(y)
@@ -348,6 +356,40 @@ def test_msm_full_size_linearity(gpu_ctx):
     assert np.array_equal(gpu_ctx.msm_g1(bases, ks), gpu_ctx.msm_g1(ps.reshape(1, 8), k))
 
 
+def test_msm_resident_2p26_linearity(gpu_ctx):
+    """The stand-alone configuration's size, 2^26 points, through zg16_bases_upload / zg16_msm_resident (window
+    tables): msm(s) + msm(t) == msm(s + t), msm(k s) == k msm(s), and a sparse scalar vector equals the small
+    multiexp over the bases it selects (which test_msm_vs_cpu_oracle pins to the oracle)."""
+    from zinc_amd import workload
+    from zinc_amd.groth16 import ResidentBases
+    rng = np.random.default_rng(2026)
+    n = 1 << 26
+    g1gen, _ = workload._generators()
+    bases = workload.fixed_base_g1(gpu_ctx, g1gen, rand_fr(rng, n))
+    res = ResidentBases(gpu_ctx, 1, bases, window_tables=True)
+    s = rand_fr(rng, n)
+    t = rand_fr(rng, n)
+    ps, pt = res.msm(s), res.msm(t)
+    step = 1 << 24  # the element-wise self-test hook takes at most 2^24 elements per call
+    chunked = lambda op, a, b: np.concatenate([_field(gpu_ctx, 0, op, a[i:i + step], b[i:i + step]) for i in range(0, n, step)])
+    s_plus_t = chunked(0, s, t)
+    pst = res.msm(s_plus_t)
+    one = ints_to_mont([1, 1], R_MOD)
+    assert np.array_equal(gpu_ctx.msm_g1(np.stack([ps, pt]), one), pst)
+    del s_plus_t, t
+    k = ints_to_mont([0xABCDEF12345], R_MOD)
+    ks = chunked(2, s, np.tile(k, (n, 1)))
+    assert np.array_equal(res.msm(ks), gpu_ctx.msm_g1(ps.reshape(1, 8), k))
+    del ks
+    # 3000 non-zero scalars scattered over the whole range (first, last, a run across the middle)
+    sparse = np.zeros((n, 4), dtype=np.uint64)
+    idx = np.unique(np.concatenate([[0, 1, n - 1, n - 2], rng.integers(0, n, size=2900), np.arange(n // 2 - 48, n // 2 + 48)]))
+    sparse[idx] = s[idx]
+    sparse[idx[::5]] = one[0]
+    assert np.array_equal(res.msm(sparse), gpu_ctx.msm_g1(bases[idx], sparse[idx]))
+    res.free()
+
+
 # ------------------------------------------------------------------------------ SpMV / prove
 @pytest.mark.parametrize("idx", [1, 2, 3])
 def test_prove_golden(gpu_ctx, idx):
@@ -377,9 +419,11 @@ def test_key_file_decoded_on_gpu(gpu_ctx, idx):
     whose proof is the golden one; damaged files are rejected the way upstream's reader rejects them."""
     from zinc_amd import codec
     from zinc_amd.groth16 import DeviceKey
+    from oracle import codec as ocodec
     fx = golden("prove_tiny_%d.json" % idx)
     circ, key = FixtureCircuit(fx), FixtureKey(fx)
-    data = codec.params_write(key)
+    data = ocodec.params_bytes(key)      # the oracle's bytes, not the product codec's
+    assert codec.params_write(key) == data and codec.vk_write(key) == ocodec.vk_bytes(key)
     pa = ProvingAssignment()
     pa.alloc_input(1)
     circ.synthesize(pa)
@@ -421,9 +465,16 @@ def test_key_file_decoded_on_gpu(gpu_ctx, idx):
     off = len(data) - 128 * len(key.b_g2)
     bad = bytearray(data); bad[off:off + 128] = codec.g2_write((x, y), False)
     assert rejected(bad)
-    # alpha_g1 (a verifying-key point) may be anything on the curve, but not off it
+    # alpha_g1 (a verifying-key point) may be anything on the curve, but not off it -- whatever `checked` says:
+    # upstream's VerifyingKey::read validates its points unconditionally
     bad = bytearray(data); bad[63] ^= 1
-    assert rejected(bad)
+    assert rejected(bad) and rejected(bad, checked=False)
+    # the identity inside ic is refused (checked or not); the identity as alpha_g1 is a valid encoding
+    ic0 = 64 * 3 + 128 * 3 + 4
+    bad = bytearray(data); bad[ic0:ic0 + 64] = bytes([0x40]) + bytes(63)
+    assert rejected(bad) and rejected(bad, checked=False)
+    ok = bytearray(data); ok[0:64] = bytes([0x40]) + bytes(63)
+    DeviceKey.from_bytes(gpu_ctx, bytes(ok), checked=True).free()
 
 
 @pytest.mark.parametrize("log_rows,dense", [(10, False), (12, True), (14, False), (16, False)])
@@ -534,6 +585,39 @@ def test_prove_full_size_verifies(gpu_ctx):
     assert not G.verify_proof(vk, p1.as_tuple(), [(public[0] + 1) % R_MOD] + public[1:])
     key.free()
     mat.free()
+
+
+def _vk_of(params):
+    class VK:
+        pass
+    vk = VK()
+    vk.alpha_g1, vk.delta_g1 = mont_to_g1(params.alpha_g1)[0], mont_to_g1(params.delta_g1)[0]
+    vk.beta_g2, vk.delta_g2, vk.gamma_g2 = (mont_to_g2(x)[0] for x in (params.beta_g2, params.delta_g2, params.gamma_g2))
+    vk.ic = mont_to_g1(params.ic)
+    return vk
+
+
+def test_prove_2p24_equals_cpu_restatement_and_verifies(gpu_ctx):
+    """2^24 rows (the large synthetic configuration; three-pass transforms, ~70 GB of key tables): the GPU proof
+    is bit-identical to the CPU restatement of bellman's prover and satisfies the Groth16 pairing equation -- the
+    reference's own bar at this boundary is verify == true (zinc-tester/src/runners/proof_check.rs:243-264)."""
+    from oracle import cpu_binding as cb, groth16 as G
+    from zinc_amd import workload
+    circ = workload.SyntheticCircuit(1 << 24)
+    params = workload.generate_parameters(gpu_ctx, circ, dict(k1=3, k2=5, alpha=7, beta=11, gamma=13, delta=17, tau=0xFACADE))
+    r1cs = circ.r1cs()
+    zi, za = circ.witness()
+    rs = ints_to_mont([0xDEADBEEF, 0xFEEDFACE], R_MOD)
+    key, mat = params.upload(gpu_ctx), r1cs.upload(gpu_ctx)
+    got = prove_recorded(gpu_ctx, key, mat, zi, za, rs[0], rs[1])
+    key.free()
+    mat.free()
+    st, want, _ = cb.prove(params, r1cs, zi, za, rs[0], rs[1], threads=min(cb.hardware_threads() or 1, 16))
+    assert st == 0
+    for g, w in zip((got.raw.a, got.raw.b, got.raw.c), want):
+        assert np.array_equal(np.frombuffer(bytes(g), dtype=np.uint64), w)
+    public = mont_to_ints(zi[1:], R_MOD)
+    assert G.verify_proof(_vk_of(params), got.as_tuple(), public)
 
 
 # ------------------------------------------------------------------------------ error behaviour

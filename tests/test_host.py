@@ -80,6 +80,33 @@ def test_params_codec_roundtrip_and_checks():
     for name in ("alpha_g1", "beta_g2", "gamma_g2", "delta_g1", "ic", "h", "l", "a", "b_g1", "b_g2"):
         assert getattr(back, name) == getattr(key, name), name
     assert data[:len(codec.vk_write(key))] == codec.vk_write(key)
+    # the product codec writes what the oracle's restatement of Parameters::write / VerifyingKey::write writes
+    from oracle import codec as ocodec
+    for idx in (1, 2, 3):
+        k = FixtureKey(golden("prove_tiny_%d.json" % idx))
+        assert codec.params_write(k) == ocodec.params_bytes(k) and codec.vk_write(k) == ocodec.vk_bytes(k)
+    assert codec.params_read(ocodec.params_bytes(key), checked=True).b_g2 == key.b_g2
+    # verifying-key points are validated whatever `checked` says, and ic may not hold the identity
+    ba = bytearray(data)
+    ba[63] ^= 1
+    with pytest.raises(codec.DecodeError):
+        codec.params_read(bytes(ba), checked=False)
+    ic0 = 64 * 3 + 128 * 3 + 4
+    ba = bytearray(data)
+    ba[ic0:ic0 + 64] = bytes([0x40]) + bytes(63)
+    with pytest.raises(codec.DecodeError):
+        codec.params_read(bytes(ba), checked=False)
+    # a twist point outside the prime-order subgroup is refused
+    x = (5, 1)
+    while True:
+        rhs = codec._fq2_mul(codec._fq2_mul(x, x), x)
+        y = codec._fq2_sqrt(((rhs[0] + codec.B_G2[0]) % codec.Q_MOD, (rhs[1] + codec.B_G2[1]) % codec.Q_MOD))
+        if y is not None:
+            break
+        x = (x[0] + 1, 1)
+    with pytest.raises(codec.DecodeError):
+        codec.g2_read(codec.g2_write((x, y), False), False, True)
+    assert codec.g2_read(codec.g2_write((x, y), False), False, False) == (x, y)
     # infinity in a query vector is rejected when checked, accepted otherwise
     key.h[0] = None
     bad = codec.params_write(key)

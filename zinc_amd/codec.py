@@ -71,6 +71,50 @@ class DecodeError(ValueError):
     pass
 
 
+R_ORDER = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+
+
+def _g2_times_order_is_identity(p):
+    """r * P == O for an affine point of the twist (Jacobian double-and-add over Fq2)."""
+    sub = lambda a, b: ((a[0] - b[0]) % Q_MOD, (a[1] - b[1]) % Q_MOD)
+    add = lambda a, b: ((a[0] + b[0]) % Q_MOD, (a[1] + b[1]) % Q_MOD)
+    mul, sqr = _fq2_mul, lambda a: _fq2_mul(a, a)
+    dbl2 = lambda a: add(a, a)
+    px, py = p
+    X, Y, Z = None, None, None  # the identity
+    for bit in bin(R_ORDER)[2:]:
+        if X is not None:
+            if Y == (0, 0):
+                X = None
+            else:  # dbl-2009-l (a = 0)
+                A, B = sqr(X), sqr(Y)
+                Cc = sqr(B)
+                D = dbl2(sub(sub(sqr(add(X, B)), A), Cc))
+                E = add(dbl2(A), A)
+                X3 = sub(sqr(E), dbl2(D))
+                Y3 = sub(mul(E, sub(D, X3)), dbl2(dbl2(dbl2(Cc))))
+                Z = dbl2(mul(Y, Z))
+                X, Y = X3, Y3
+        if bit == "1":
+            if X is None:
+                X, Y, Z = px, py, (1, 0)
+            else:  # mixed addition
+                Z2 = sqr(Z)
+                U2, S2 = mul(px, Z2), mul(py, mul(Z2, Z))
+                if U2 == X:
+                    if S2 != Y:
+                        X = None
+                        continue
+                    raise AssertionError("doubling inside an addition cannot happen for a point of odd prime order")
+                H, Rr = sub(U2, X), sub(S2, Y)
+                H2 = sqr(H)
+                H3, V = mul(H, H2), mul(X, H2)
+                X3 = sub(sub(sqr(Rr), H3), dbl2(V))
+                Y = sub(mul(Rr, sub(V, X3)), mul(Y, H3))
+                X, Z = X3, mul(Z, H)
+    return X is None or Z == (0, 0)
+
+
 # ------------------------------------------------------------------------------ single points
 def g1_write(p, compressed):
     if p is None:
@@ -143,8 +187,11 @@ def g2_read(buf, compressed, checked=True):
             y = ny
         return (x, y)
     y = (_int(buf[96:128]), _int(buf[64:96]))
-    if checked and _fq2_mul(y, y) != rhs:
-        raise DecodeError("point is not on the curve")
+    if checked:
+        if _fq2_mul(y, y) != rhs:
+            raise DecodeError("point is not on the curve")
+        if not _g2_times_order_is_identity((x, y)):
+            raise DecodeError("point is not in the prime-order subgroup")
     return (x, y)
 
 
@@ -185,16 +232,21 @@ def _read_exact(f, n):
     return b
 
 
-def vk_read(f, pk=None, checked=True):
+def vk_read(f, pk=None):
+    """bellman `VerifyingKey::read`: every point goes through `into_affine()` (on the curve, in the
+    subgroup) whatever the caller's `checked` flag for the query vectors says, and ic may not hold
+    the point at infinity."""
     pk = pk or KeyPoints()
-    pk.alpha_g1 = g1_read(_read_exact(f, 64), False, checked)
-    pk.beta_g1 = g1_read(_read_exact(f, 64), False, checked)
-    pk.beta_g2 = g2_read(_read_exact(f, 128), False, checked)
-    pk.gamma_g2 = g2_read(_read_exact(f, 128), False, checked)
-    pk.delta_g1 = g1_read(_read_exact(f, 64), False, checked)
-    pk.delta_g2 = g2_read(_read_exact(f, 128), False, checked)
+    pk.alpha_g1 = g1_read(_read_exact(f, 64), False, True)
+    pk.beta_g1 = g1_read(_read_exact(f, 64), False, True)
+    pk.beta_g2 = g2_read(_read_exact(f, 128), False, True)
+    pk.gamma_g2 = g2_read(_read_exact(f, 128), False, True)
+    pk.delta_g1 = g1_read(_read_exact(f, 64), False, True)
+    pk.delta_g2 = g2_read(_read_exact(f, 128), False, True)
     n = int.from_bytes(_read_exact(f, 4), "big")
-    pk.ic = [g1_read(_read_exact(f, 64), False, checked) for _ in range(n)]
+    pk.ic = [g1_read(_read_exact(f, 64), False, True) for _ in range(n)]
+    if any(p is None for p in pk.ic):
+        raise DecodeError("point at infinity in ic")
     return pk
 
 
@@ -212,7 +264,7 @@ def params_read(data, checked=True):
     """bellman `Parameters::read(reader, checked)`: with `checked`, points must be on the curve and
     the query vectors may not contain the point at infinity."""
     f = io.BytesIO(data) if isinstance(data, (bytes, bytearray)) else data
-    pk = vk_read(f, KeyPoints(), checked)
+    pk = vk_read(f, KeyPoints())
     for name in ("h", "l", "a", "b_g1"):
         n = int.from_bytes(_read_exact(f, 4), "big")
         vec = [g1_read(_read_exact(f, 64), False, checked) for _ in range(n)]

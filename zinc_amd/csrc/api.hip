@@ -219,6 +219,8 @@ zg16_status zg16_pk_upload(zg16_ctx* ctx, const zg16_pk_view* v, int shard_index
   if (!v->alpha_g1 || !v->beta_g1 || !v->beta_g2 || !v->delta_g1 || !v->delta_g2)
     return fail(ctx, ZG16_ERR_MALFORMED_KEY, "verifying-key points missing");
   if (v->n_b_g1 != v->n_b_g2) return fail(ctx, ZG16_ERR_MALFORMED_KEY, "b_g1 and b_g2 lengths differ");
+  if ((v->n_h && !v->h) || (v->n_l && !v->l) || (v->n_a && !v->a) || (v->n_b_g1 && !v->b_g1) || (v->n_b_g2 && !v->b_g2))
+    return fail(ctx, ZG16_ERR_MALFORMED_KEY, "a query vector has a length but no points");
   ZG_HIP(ctx, hipSetDevice(ctx->device));
   std::unique_ptr<zg16_pk, void (*)(zg16_pk*)> pk(new zg16_pk(), zg16_pk_free);
   pk->ctx = ctx;
@@ -572,6 +574,10 @@ static zg16_status prove_partial_impl(zg16_ctx* ctx, const zg16_pk* pk, const zg
     }
   }
   mark("everything enqueued");
+  // From here on the proof is in flight on several streams.  Any failure while collecting it (an identity base
+  // reported by a multiexp, a failed event query) leaves through the single exit below, which lets the GPU drain
+  // and returns the timers' events to the pool before the caller can reuse or free what the kernels touch.
+  auto collect = [&]() -> zg16_status {
   if (host_trace && !graphed) {  // when the GPU passes each stage boundary, on the host's clock
     const int ids[] = {E_Z, E_SPMV, E_NTT, E_G2_END, E_Z_END, E_G1, E_END};
     const char* names[] = {"gpu: witness staged", "gpu: rows done", "gpu: transforms done", "gpu: G2 multiexp done",
@@ -656,6 +662,13 @@ static zg16_status prove_partial_impl(zg16_ctx* ctx, const zg16_pk* pk, const zg
   profile_collect(ctx);
   mark("timings read");
   return ZG16_OK;
+  };  // collect
+  const zg16_status cs = collect();
+  if (cs != ZG16_OK) {
+    (void)hipDeviceSynchronize();
+    profile_collect(ctx);
+  }
+  return cs;
 }
 
 extern "C" {
@@ -913,19 +926,11 @@ zg16_status zg16_bases_upload(zg16_ctx* ctx, int group, const uint64_t* bases, s
   b->group = group;
   b->n = n;
   b->table_c = window_tables ? msm_table_window(n, 0) : 0;
-  if (group == 1) {
-    Affine<Fq>* p;
-    Affine<Fq>* d;
-    ZG_TRY(upload_query<Fq>(ctx, &p, bases, n, b->table_c, &d));
-    b->points = p;
-    b->direct = d;
-  } else {
-    Affine<Fq2>* p;
-    Affine<Fq2>* d;
-    ZG_TRY(upload_query<Fq2>(ctx, &p, bases, n, b->table_c, &d));
-    b->points = p;
-    b->direct = d;
-  }
+  // the handle's fields receive the arrays as they are allocated, so zg16_bases_free releases them on any failure
+  if (group == 1)
+    ZG_TRY(upload_query<Fq>(ctx, (Affine<Fq>**)&b->points, bases, n, b->table_c, (Affine<Fq>**)&b->direct));
+  else
+    ZG_TRY(upload_query<Fq2>(ctx, (Affine<Fq2>**)&b->points, bases, n, b->table_c, (Affine<Fq2>**)&b->direct));
   *out = b.release();
   return ZG16_OK;
 }

@@ -189,17 +189,19 @@ zg16_status zg16_pk_upload_bytes(zg16_ctx* ctx, const uint8_t* data, size_t len,
   pk->shard_index = shard_index;
   pk->shard_count = shard_count;
 
-  // verifying key: six points, then the ic vector (not used by the prover, still validated)
+  // verifying key: six points, then the ic vector (not used by the prover, still validated).  bellman's
+  // VerifyingKey::read converts every one of them with into_affine() -- on the curve and in the subgroup -- whatever
+  // `checked` says (that flag only governs the five query vectors), and refuses the identity inside ic.
   const uint8_t* b;
   uint32_t e;
-  auto g1 = [&](G1Affine* dst, const char* what) -> zg16_status {
+  auto g1 = [&](G1Affine* dst, const char* what, bool allow_inf = true) -> zg16_status {
     if (!cur.take(64, &b)) return eof();
-    if ((e = decode_g1(b, checked != 0, true, dst))) return fail(ctx, ZG16_ERR_MALFORMED_KEY, "%s: %s", what, decode_text(e));
+    if ((e = decode_g1(b, true, allow_inf, dst))) return fail(ctx, ZG16_ERR_MALFORMED_KEY, "%s: %s", what, decode_text(e));
     return ZG16_OK;
   };
   auto g2 = [&](G2Affine* dst, const char* what) -> zg16_status {
     if (!cur.take(128, &b)) return eof();
-    if ((e = decode_g2(b, checked != 0, true, curve_b, dst))) return fail(ctx, ZG16_ERR_MALFORMED_KEY, "%s: %s", what, decode_text(e));
+    if ((e = decode_g2(b, true, true, curve_b, dst))) return fail(ctx, ZG16_ERR_MALFORMED_KEY, "%s: %s", what, decode_text(e));
     return ZG16_OK;
   };
   G2Affine gamma2;
@@ -214,7 +216,7 @@ zg16_status zg16_pk_upload_bytes(zg16_ctx* ctx, const uint8_t* data, size_t len,
   if (!cur.u32be(&n_ic)) return eof();
   for (size_t i = 0; i < n_ic; i++) {
     G1Affine ic;
-    ZG_TRY(g1(&ic, "ic"));
+    ZG_TRY(g1(&ic, "ic", false));
   }
 
   // the five query vectors: locate them first, then decode this shard's ranges on the GPU

@@ -177,11 +177,11 @@ __global__ __launch_bounds__(256) void k_sort_count(JobTable<F> jt, MsmShape sh,
   }
 }
 
-// One workgroup: coff = exclusive scan of chist[0..nbins) (coff[nbins] = total), ccursor = copy of it (unused now),
-// and hist[nb + g] = number of unit scalars of group g so that the bucket scan places them too.
+// One workgroup: coff = exclusive scan of chist[0..nbins) (coff[nbins] = total), and hist[nb + g] = number of
+// unit scalars of group g so that the bucket scan places them too.
 __global__ __launch_bounds__(1024) void k_scan_coarse(const uint32_t* __restrict__ chist, uint32_t ncoarse, uint32_t G,
-                                                      uint32_t* __restrict__ coff, uint32_t* __restrict__ ccursor,
-                                                      uint32_t* __restrict__ hist, uint32_t nb) {
+                                                      uint32_t* __restrict__ coff, uint32_t* __restrict__ hist,
+                                                      uint32_t nb) {
   __shared__ uint32_t part[1024];
   const uint32_t tid = threadIdx.x, nbins = ncoarse + G;
   // nbins <= SORT_MAX_COARSE + MAX_JOBS: two counters per lane cover it
@@ -195,8 +195,8 @@ __global__ __launch_bounds__(1024) void k_scan_coarse(const uint32_t* __restrict
     __syncthreads();
   }
   const uint32_t excl = tid ? part[tid - 1] : 0;
-  if (2 * tid < nbins) { coff[2 * tid] = excl; ccursor[2 * tid] = excl; }
-  if (2 * tid + 1 < nbins) { coff[2 * tid + 1] = excl + v0; ccursor[2 * tid + 1] = excl + v0; }
+  if (2 * tid < nbins) coff[2 * tid] = excl;
+  if (2 * tid + 1 < nbins) coff[2 * tid + 1] = excl + v0;
   if (tid == 1023) coff[nbins] = part[1023];
   if (tid < G) hist[nb + tid] = chist[ncoarse + tid];
 }
@@ -936,7 +936,6 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
   const size_t o_cur = o;    o += align((size_t)ncount * 4);
   const size_t o_chist = o;  o += align((size_t)nbins * 4);
   const size_t o_coff = o;   o += align((size_t)(nbins + 1) * 4);
-  const size_t o_ccur = o;   o += align((size_t)nbins * 4);
   const size_t o_err = o;    o += 256;  // [0] identity-base flag, [2] number of heavy buckets
   const size_t o_zero_end = o;
   const size_t o_rec0 = o;   o += align(max_entries * sizeof(uint2));  // coarse-sorted entries
@@ -975,7 +974,6 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
   uint32_t* cursor = (uint32_t*)(base + o_cur);
   uint32_t* chist = (uint32_t*)(base + o_chist);
   uint32_t* coff = (uint32_t*)(base + o_coff);
-  uint32_t* ccursor = (uint32_t*)(base + o_ccur);
   uint32_t* err = (uint32_t*)(base + o_err);
   uint2* rec0 = (uint2*)(base + o_rec0);
   uint2* rec = (uint2*)(base + o_rec);
@@ -994,7 +992,7 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
     KernelTimer kt(ctx, K_MSM_DIGITS, (double)n, st);
     const unsigned fgrid = (unsigned)((max_entries + FINE_TILE - 1) / FINE_TILE);
     k_sort_count<F><<<sgrid, 256, 0, st>>>(jt, sh, ss, chist, wg_hist);
-    k_scan_coarse<<<1, 1024, 0, st>>>(chist, ss.ncoarse, sh.G, coff, ccursor, hist, sh.nb);
+    k_scan_coarse<<<1, 1024, 0, st>>>(chist, ss.ncoarse, sh.G, coff, hist, sh.nb);
     // exclusive scan of the (bin, workgroup) histogram, in place: every workgroup's run start in every bin
     k_scan_local<<<wg_tiles, 256, 0, st>>>(wg_hist, (uint32_t)n_wgh, wg_hist, wg_tiles_sum);
     k_scan_tiles<<<1, 1024, 0, st>>>(wg_tiles_sum, wg_tiles);
