@@ -240,6 +240,17 @@ zg16_status zg16_bases_upload(zg16_ctx* ctx, int group, const uint64_t* bases, s
 void        zg16_bases_free(zg16_bases* bases);
 zg16_status zg16_msm_resident(zg16_ctx* ctx, const zg16_bases* bases, const uint64_t* scalars,
                               int scalars_on_device, uint64_t* out);
+/* zg16_msm_resident for callers that cannot allocate (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc): the same sum, computed in a fixed device array that is part of the
+ * library image (about 0.8 MB per GPU, held until the process ends) instead of the context's grow-only
+ * scratch arena.  No counterpart in the reference.  The call performs no hipMalloc / hipFree and uses no
+ * allocating library routine.  Limits: the base set must have been uploaded with window_tables != 0 and hold
+ * at most 16384 points (and no more than the direct-table limit of the upload, 2^14 unless
+ * ZG16_DIRECT_MAX_LOG lowered it); anything else is ZG16_ERR_INVALID_ARGUMENT.  Scalars as for
+ * zg16_msm_resident (host scalars are staged inside the same array).  All calls on one GPU share the array:
+ * calls that overlap on one GPU -- from any context or thread -- race. */
+zg16_status zg16_msm_resident_noalloc(zg16_ctx* ctx, const zg16_bases* bases, const uint64_t* scalars,
+                                      int scalars_on_device, uint64_t* out);
 /* Row evaluations <A_row, z>, <B_row, z>, <C_row, z> (n_rows Montgomery Fr each, host memory). */
 zg16_status zg16_spmv(zg16_ctx* ctx, const zg16_r1cs* r1cs, const uint64_t* z_in,
                       const uint64_t* z_aux, uint64_t* a, uint64_t* b, uint64_t* c);

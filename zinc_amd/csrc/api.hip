@@ -180,6 +180,10 @@ zg16_status zg16_ctx_create(int device_id, zg16_ctx** out) {
       delete ctx;
       return ZG16_ERR_DEVICE;
     }
+  if (msm_noalloc_init(ctx) != ZG16_OK) {
+    zg16_ctx_destroy(ctx);
+    return ZG16_ERR_DEVICE;
+  }
   *out = ctx;
   return ZG16_OK;
 }

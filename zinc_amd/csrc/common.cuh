@@ -232,11 +232,21 @@ struct MsmStreams {
   hipStream_t side;             // optional: the unit-scalar sums run here beside the bucket pipeline
   hipEvent_t ev_fork, ev_join;  // used when side is set
 };
+// fixed: when given, the multiexp works in this caller-owned device memory instead of the context's scratch arena and
+// allocates nothing; only launches whose jobs all bring direct tables fit that mode.
+struct MsmWorkspace {
+  char* ptr;
+  size_t bytes;
+};
 template <class F>
 zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, void* pinned, const MsmJob<F>* jobs,
-                       int njobs, int ngroups, MsmPending* pend);
+                       int njobs, int ngroups, MsmPending* pend, const MsmWorkspace* fixed = nullptr);
 template <class F>
 zg16_status msm_collect(zg16_ctx* ctx, const MsmPending* pend, XYZZ<F>* out);
+
+// Looks up this GPU's copy of the static workspace behind zg16_msm_resident_noalloc (once per device; the
+// context's device must be current).
+zg16_status msm_noalloc_init(zg16_ctx* ctx);
 
 void ntt_free_domains(zg16_ctx* ctx);
 void ntt_free_cross_tables(zg16_ctx* ctx);

@@ -31,9 +31,11 @@
 //   7. host              : sum_b (b+1)*S_b from the folded sums; Horner over the W window sums
 //                          (per-window layout only)
 #define ZG_OUTLINE_FIELD_MUL 1
+#include <string.h>
+
 #include <algorithm>
 
-#include "common.cuh"
+#include "r1cs.cuh"
 #include "msm_ops.cuh"
 
 namespace zg {
@@ -835,7 +837,7 @@ static constexpr size_t PINNED_POINTS = 256;
 
 template <class F>
 zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, void* pinned, const MsmJob<F>* jobs,
-                       int njobs, int ngroups, MsmPending* pend) {
+                       int njobs, int ngroups, MsmPending* pend, const MsmWorkspace* fixed) {
   hipStream_t st = ms.main;
   if (njobs > MAX_JOBS) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "too many multiexp jobs");
   if (ngroups < 1 || ngroups > MAX_JOBS) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "bad multiexp group count");
@@ -882,13 +884,23 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
     if (blocks > 1024) blocks = 1024;
     auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t o_part = 256, o_out = o_part + align((size_t)nj * blocks * sizeof(PtMem));
+    const size_t need = o_out + align((size_t)nj * sizeof(XYZZ<F>));
     char* base;
-    ZG_TRY(scratch_get(ctx, scratch_slot, o_out + align((size_t)nj * sizeof(XYZZ<F>)), (void**)&base));
+    if (fixed) {
+      // a caller-supplied workspace: nothing is allocated (the per-kernel timers create events, so they stay off)
+      if (need > fixed->bytes) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "multiexp needs %zu bytes of workspace, %zu given", need, fixed->bytes);
+      base = fixed->ptr;
+    } else {
+      ZG_TRY(scratch_get(ctx, scratch_slot, need, (void**)&base));
+    }
     uint32_t* err = (uint32_t*)base;
     PtMem* part = (PtMem*)(base + o_part);
     XYZZ<F>* wstd = (XYZZ<F>*)(base + o_out);
     ZG_HIP(ctx, hipMemsetAsync(base, 0, 256, st));
-    {
+    if (fixed) {
+      k_direct_sum<F><<<dim3(blocks, nj), 256, 0, st>>>(jt, direct_bias(), part, err);
+      k_sum_partials<F><<<nj, 256, 0, st>>>(part, blocks, wstd);
+    } else {
       KernelTimer kt(ctx, sizeof(F) > sizeof(Fq) ? K_MSM_ONES_G2 : K_MSM_ONES_G1, (double)n, st);
       k_direct_sum<F><<<dim3(blocks, nj), 256, 0, st>>>(jt, direct_bias(), part, err);
       k_sum_partials<F><<<nj, 256, 0, st>>>(part, blocks, wstd);
@@ -902,6 +914,7 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
     return ZG16_OK;
   }
 
+  if (fixed) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "a multiexp in a fixed workspace needs a direct table for every job");
   MsmShape sh;
   sh.n = (uint32_t)n;
   sh.shared = all_tables ? 1 : 0;
@@ -1138,8 +1151,10 @@ zg16_status msm_collect(zg16_ctx* ctx, const MsmPending* pend, XYZZ<F>* out) {
   return ZG16_OK;
 }
 
-template zg16_status msm_launch<Fq>(zg16_ctx*, const MsmStreams&, int, void*, const MsmJob<Fq>*, int, int, MsmPending*);
-template zg16_status msm_launch<Fq2>(zg16_ctx*, const MsmStreams&, int, void*, const MsmJob<Fq2>*, int, int, MsmPending*);
+template zg16_status msm_launch<Fq>(zg16_ctx*, const MsmStreams&, int, void*, const MsmJob<Fq>*, int, int, MsmPending*,
+                                    const MsmWorkspace*);
+template zg16_status msm_launch<Fq2>(zg16_ctx*, const MsmStreams&, int, void*, const MsmJob<Fq2>*, int, int, MsmPending*,
+                                     const MsmWorkspace*);
 template zg16_status msm_collect<Fq>(zg16_ctx*, const MsmPending*, XYZZ<Fq>*);
 template zg16_status msm_collect<Fq2>(zg16_ctx*, const MsmPending*, XYZZ<Fq2>*);
 
@@ -1159,4 +1174,72 @@ zg16_status msm_g2_device(zg16_ctx* ctx, const MsmJob<Fq2>* jobs, int njobs, G2X
   return msm_blocking<Fq2>(ctx, 2, jobs, njobs, out_host);
 }
 
+
+// ---- a multiexp that allocates nothing ------------------------------------------------------------
+// zg16_msm_resident_noalloc works in one file-scope device array instead of the context's grow-only scratch
+// arena: the partial sums of k_direct_sum's workgroups, the identity-base flag, the result block and (for host
+// scalars) the staged scalars.  Every GPU holds its own copy of the array for the life of the process; its device
+// address is looked up once per device when a context is created there, and only that address is ever handed to a
+// kernel, a memset or a copy.  All calls on one GPU share the array, so calls that overlap on one GPU race.
+static constexpr size_t NOALLOC_MAX_POINTS = (size_t)1 << 14;
+static constexpr size_t NOALLOC_MSM_BYTES = 256 + 1024 * sizeof(MsmOps<Fq2>::PtMem) + 256;  // flags, partials, result
+static constexpr size_t NOALLOC_BYTES = NOALLOC_MSM_BYTES + NOALLOC_MAX_POINTS * sizeof(Fr);
+static constexpr int NOALLOC_MAX_DEVICES = 64;
+static __device__ __align__(256) unsigned char scratch[NOALLOC_BYTES];
+static unsigned char* g_scratch_ptr[NOALLOC_MAX_DEVICES] = {};
+
+// Called by zg16_ctx_create with the context's device current.
+zg16_status msm_noalloc_init(zg16_ctx* ctx) {
+  if (ctx->device < 0 || ctx->device >= NOALLOC_MAX_DEVICES) return ZG16_OK;  // the entry point reports it
+  if (g_scratch_ptr[ctx->device]) return ZG16_OK;
+  unsigned char* ptr = nullptr;
+  ZG_HIP(ctx, hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
+  g_scratch_ptr[ctx->device] = ptr;
+  return ZG16_OK;
+}
+
 }  // namespace zg
+
+using namespace zg;
+
+extern "C" zg16_status zg16_msm_resident_noalloc(zg16_ctx* ctx, const zg16_bases* b, const uint64_t* scalars,
+                                                 int on_device, uint64_t* out) {
+  if (!ctx || !b || !out || (b->n && !scalars)) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "bad arguments to zg16_msm_resident_noalloc");
+  if (b->ctx != ctx) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "handle belongs to another context");
+  if (b->n > NOALLOC_MAX_POINTS)
+    return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "zg16_msm_resident_noalloc takes at most %zu points, the base set has %zu",
+                NOALLOC_MAX_POINTS, b->n);
+  if (b->n && !b->direct)
+    return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "zg16_msm_resident_noalloc needs a base set uploaded with window tables and small "
+                                                "enough for a direct table (%zu points)", msm_direct_max());
+  ZG_HIP(ctx, hipSetDevice(ctx->device));
+  unsigned char* ws = ctx->device < NOALLOC_MAX_DEVICES ? g_scratch_ptr[ctx->device] : nullptr;
+  if (!ws) return fail(ctx, ZG16_ERR_DEVICE, "no static workspace on GPU %d", ctx->device);
+  const Fr* d_s = (const Fr*)scalars;
+  if (!on_device && b->n) {
+    Fr* staged = (Fr*)(ws + NOALLOC_MSM_BYTES);
+    ZG_HIP(ctx, hipMemcpyAsync(staged, scalars, b->n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    d_s = staged;
+  }
+  const MsmWorkspace fixed = {(char*)ws, NOALLOC_MSM_BYTES};
+  const MsmStreams ms = {ctx->stream, nullptr, nullptr, nullptr};
+  MsmPending pend;
+  if (b->group == 1) {
+    const MsmJob<Fq> job = {(const Affine<Fq>*)b->points, d_s, nullptr, b->n, b->n, b->table_c, 0, (const Affine<Fq>*)b->direct};
+    ZG_TRY(msm_launch<Fq>(ctx, ms, 1, ctx->pinned, &job, 1, 1, &pend, &fixed));
+    ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    G1XYZZ res;
+    ZG_TRY(msm_collect<Fq>(ctx, &pend, &res));
+    const G1Affine a = to_affine(res);
+    memcpy(out, &a, sizeof a);
+  } else {
+    const MsmJob<Fq2> job = {(const Affine<Fq2>*)b->points, d_s, nullptr, b->n, b->n, b->table_c, 0, (const Affine<Fq2>*)b->direct};
+    ZG_TRY(msm_launch<Fq2>(ctx, ms, 2, ctx->pinned, &job, 1, 1, &pend, &fixed));
+    ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    G2XYZZ res;
+    ZG_TRY(msm_collect<Fq2>(ctx, &pend, &res));
+    const G2Affine a = to_affine(res);
+    memcpy(out, &a, sizeof a);
+  }
+  return ZG16_OK;
+}

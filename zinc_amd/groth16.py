@@ -146,8 +146,10 @@ class ResidentBases:
         _check(ctx.handle, ctx._lib.zg16_bases_upload(ctx.handle, group, arr.ctypes.data_as(C.c_void_p), self.n,
                                                       int(window_tables), C.byref(self.handle)))
 
-    def msm(self, scalars=None, device_ptr=None):
-        """Sum of scalars[i] * base[i]; scalars are Montgomery Fr on the host, or `device_ptr` on the GPU."""
+    def msm(self, scalars=None, device_ptr=None, noalloc=False):
+        """Sum of scalars[i] * base[i]; scalars are Montgomery Fr on the host, or `device_ptr` on the GPU.
+        noalloc: go through zg16_msm_resident_noalloc (small base sets with window tables only)."""
+        fn = self.ctx._lib.zg16_msm_resident_noalloc if noalloc else self.ctx._lib.zg16_msm_resident
         out = np.zeros(self.width, dtype=np.uint64)
         if device_ptr is not None:
             ptr, on_dev = C.c_void_p(device_ptr), 1
@@ -155,7 +157,7 @@ class ResidentBases:
             sc = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
             assert sc.shape[0] == self.n
             ptr, on_dev = sc.ctypes.data_as(C.c_void_p), 0
-        _check(self.ctx.handle, self.ctx._lib.zg16_msm_resident(self.ctx.handle, self.handle, ptr, on_dev, _lib.as_u64p(out)))
+        _check(self.ctx.handle, fn(self.ctx.handle, self.handle, ptr, on_dev, _lib.as_u64p(out)))
         return out
 
     def free(self):

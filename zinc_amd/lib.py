@@ -97,6 +97,7 @@ SYMBOLS = [
     ("zg16_bases_upload", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]),
     ("zg16_bases_free", None, [C.c_void_p]),
     ("zg16_msm_resident", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, u64p]),
+    ("zg16_msm_resident_noalloc", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, u64p]),
     ("zg16_spmv", C.c_int, [C.c_void_p, C.c_void_p, u64p, u64p, u64p, u64p, u64p]),
     ("zg16_fixed_base_g1", C.c_int, [C.c_void_p, u64p, u64p, C.c_size_t, u64p]),
     ("zg16_fixed_base_g2", C.c_int, [C.c_void_p, u64p, u64p, C.c_size_t, u64p]),
