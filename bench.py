@@ -48,6 +48,10 @@ def parse():
                     help="leave the per-kernel HIP-event timers off (no roofline in the output): shows what they cost")
     ap.add_argument("--graph", choices=("auto", "on", "off"), default="auto",
                     help="HIP-graph replay of the proof (auto: off unless ZG16_GRAPH=1); only proofs without kernel timers replay")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary measurements (2^24 prove, dense 2^20, stand-alone 2^26 multiexp / transform, cold start)")
+    ap.add_argument("--secondary-log-rows", type=int, default=24, help="circuit size of the secondary large prove")
+    ap.add_argument("--secondary-log-n", type=int, default=26, help="size of the stand-alone multiexp / transform")
     ap.add_argument("--split-transforms", choices=("auto", "on", "off"), default="auto",
                     help="run the A/B/C transform chains on different ranks (auto: 3+ ranks and 2^22+ rows)")
     return ap.parse_args()
@@ -87,10 +91,262 @@ def cpu_baseline_leg(ctx, log_rows, dense, reuse=None):
             "gpu_proof_identical": bool(same)}
 
 
+class Dist:
+    """What the measurement helpers need from the process group: rank layout, a fence, a max over ranks."""
+
+    def __init__(self, rank, world, backend, local_rank):
+        import torch
+        self.rank, self.world, self.backend, self.local_rank = rank, world, backend, local_rank
+        self.torch = torch
+        self.dev = torch.device("cuda", local_rank)
+
+    def fence(self):
+        if self.world > 1:
+            self.torch.distributed.barrier()
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, value):
+        if self.world == 1:
+            return value
+        t = self.torch.tensor([value], dtype=self.torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
+        self.torch.distributed.all_reduce(t, op=self.torch.distributed.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed(self, fn, reps, warmup=1):
+        """Average seconds per call over `reps` calls after `warmup`, fenced on both sides, max over ranks."""
+        for _ in range(warmup):
+            fn()
+        self.fence()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        self.fence()
+        return self.max_over_ranks((time.perf_counter() - t0) / reps)
+
+
+def rand_fr(rng, count):
+    """`count` valid Montgomery representations (below 2^251 < r) as (count, 4) uint64."""
+    a = rng.integers(0, 1 << 63, size=(count, 4), dtype=np.uint64)
+    a[:, 3] &= np.uint64((1 << 59) - 1)
+    return a
+
+
+class ProveCase:
+    """One synthetic circuit with its key, matrices and witness resident in HBM (this rank's key shard)."""
+
+    def __init__(self, ctx, d, log_rows, dense, split):
+        import torch
+        from zinc_amd import workload
+        from zinc_amd.fields import ints_to_mont, R_MOD
+        self.ctx, self.d, self.log_rows, self.dense, self.split = ctx, d, log_rows, dense, split
+        t0 = time.time()
+        self.circ = workload.SyntheticCircuit(1 << log_rows, dense=dense)
+        self.params = workload.generate_parameters(ctx, self.circ, TOXIC)
+        self.r1cs = self.circ.r1cs()
+        self.generate_s = time.time() - t0
+        t0 = time.time()
+        self.key = self.params.upload(ctx, d.rank, d.world)
+        self.mat = self.r1cs.upload(ctx)
+        self.zi, self.za = self.circ.witness()
+        self.z_in_dev = torch.from_numpy(self.zi.view(np.int64)).cuda()
+        self.z_aux_dev = torch.from_numpy(self.za.view(np.int64)).cuda()
+        torch.cuda.synchronize()
+        self.upload_s = time.time() - t0
+        # full-size r, s as Fr::rand gives
+        self.rs = ints_to_mont([pow(7, 123456789, R_MOD), pow(5, 987654321, R_MOD)], R_MOD)
+        self.pk_view = self.params.view()
+
+    def step(self):
+        from zinc_amd.distributed import prove_sharded
+        d = self.d
+        return prove_sharded(self.ctx, self.key, self.mat, self.z_in_dev.data_ptr(), self.z_aux_dev.data_ptr(), 1,
+                             self.pk_view, self.rs[0], self.rs[1], d.rank, d.world, d.dev if d.world > 1 else None,
+                             split_transforms=self.split)
+
+    def free(self):
+        self.key.free()
+        self.mat.free()
+        del self.z_in_dev, self.z_aux_dev
+
+
+def accumulate_roofline(stats, name="k_accumulate<G1>", fq_mul=FQ_MUL_PER_G1_MADD):
+    ms, launches, adds = stats[name]
+    if not launches:
+        return None
+    ach = adds * fq_mul * MAD_PER_FQ_MUL / (ms * 1e-3)
+    return {"kernel": name, "bound": "valu", "achieved": ach / 1e12, "peak": VALU_MAD_PEAK / 1e12, "unit": "Tmad/s",
+            "frac": ach / VALU_MAD_PEAK, "traffic": None, "avg_launch_ms": ms / launches, "adds_per_launch": adds / launches,
+            "frac_of_measured_mad_rate": ach / VALU_MAD_MEASURED}
+
+
+def secondary_block(ctx, d, args, split_for):
+    """Measurements beside the headline, each after its own warm-up and with inputs resident in HBM:
+    the large synthetic prove, the dense-witness 2^20 prove, the stand-alone G1 multiexp and Fr transform of the
+    stand-alone configuration, and a cold start (key upload + table expansion + matrices + first proof).  Every rank
+    takes part; the values are maxima over ranks.  A stage that fails is reported as {"error": ...} and the others
+    still run."""
+    import torch
+    from zinc_amd import workload
+    from zinc_amd.distributed import ntt_sharded
+    from zinc_amd.groth16 import ResidentBases, _check
+    out = {}
+
+    def guarded(name, fn):
+        try:
+            out[name] = fn()
+        except Exception as e:  # noqa: BLE001 -- a secondary stage must not take the headline line down with it
+            out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if d.world > 1:
+            torch.distributed.barrier()
+
+    def prove_case(log_rows, dense, reps):
+        case = ProveCase(ctx, d, log_rows, dense, split_for(log_rows))
+        try:
+            case.step()
+            ctx.profile(2, reset=True)
+            sec = d.timed(case.step, reps, warmup=1)
+            stats = ctx.kernel_stats()
+            stage = ctx.timings()
+            ctx.profile(False, reset=False)
+            n_rows = 1 << log_rows
+            return {"workload": "synthetic zinc-shaped R1CS, 2^%d rows (%s witness), full Groth16 prove incl. G2 multiexp"
+                                % (log_rows, "dense" if dense else "80% bit"),
+                    "ms_per_proof": 1e3 * sec, "constraints_per_s": n_rows / sec, "proofs_timed": reps,
+                    "stage_ms_last_proof": stage, "roofline": accumulate_roofline(stats),
+                    "generate_s_untimed": case.generate_s, "key_upload_and_tables_s": case.upload_s,
+                    "split_transforms": bool(case.split)}
+        finally:
+            case.free()
+
+    def cold_start():
+        """What a process that proves once pays: key expansion into window tables, matrices, first proof (tables of
+        the transform included), against the resident-handle latency of the headline."""
+        from zinc_amd.groth16 import prove_recorded
+        log_rows = min(args.log_rows, 20)
+        circ = workload.SyntheticCircuit(1 << log_rows)
+        params = workload.generate_parameters(ctx, circ, TOXIC)
+        r1cs = circ.r1cs()
+        zi, za = circ.witness()
+        cold = zinc_amd_context(d.local_rank)  # a fresh context: no cached transform tables, no scratch arenas
+        try:
+            d.fence()
+            t0 = time.perf_counter()
+            key = params.upload(cold, d.rank, d.world)
+            t1 = time.perf_counter()
+            mat = r1cs.upload(cold)
+            t2 = time.perf_counter()
+            part = workload_first_proof(cold, key, mat, zi, za, params, d)
+            t3 = time.perf_counter()
+            key.free()
+            mat.free()
+        finally:
+            cold.close()
+        return {"workload": "2^%d rows: zg16_pk_upload (window tables) + zg16_r1cs_upload + first proof from host witness" % log_rows,
+                "key_upload_and_tables_s": d.max_over_ranks(t1 - t0), "matrices_upload_s": d.max_over_ranks(t2 - t1),
+                "first_proof_s": d.max_over_ranks(t3 - t2), "total_s": d.max_over_ranks(t3 - t0)}
+
+    def ntt_standalone():
+        log_n = args.secondary_log_n
+        n_loc = (1 << log_n) // d.world
+        rng = np.random.default_rng(1 + d.rank)
+        x = torch.from_numpy(rand_fr(rng, n_loc).view(np.int64)).to(d.dev)
+        res = {}
+        for inverse in (0, 1):
+            if d.world == 1:
+                fn = lambda: _check(ctx.handle, ctx._lib.zg16_ntt(ctx.handle, C.c_void_p(x.data_ptr()), log_n, inverse, 0, 1))
+            else:
+                holder = [x]
+
+                def fn():
+                    holder[0] = ntt_sharded(ctx, holder[0], log_n, d.rank, d.world, bool(inverse), d.dev)
+            res[inverse] = d.timed(fn, 5, warmup=2)
+        nbytes = 64.0 * (1 << log_n)
+        return {"workload": "Fr transform of 2^%d uniform elements, natural order in and out%s"
+                            % (log_n, "" if d.world == 1 else ", sharded over %d GPUs with one all-to-all" % d.world),
+                "fft_ms": 1e3 * res[0], "ifft_ms": 1e3 * res[1], "elements_per_s": (1 << log_n) / res[0],
+                "roofline": {"kernel": "k_ntt_pass (whole transform)", "bound": "hbm", "achieved": nbytes / res[0] / 1e9,
+                             "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": nbytes / res[0] / HBM_PEAK, "traffic": None,
+                             "bytes_per_transform": nbytes}}
+
+    def msm_standalone():
+        log_n = args.secondary_log_n
+        n = 1 << log_n
+        n_loc = n // d.world
+        rng = np.random.default_rng(100 + d.rank)
+        g1gen, _ = workload._generators()
+        t0 = time.time()
+        bases = workload.fixed_base_g1(ctx, g1gen, rand_fr(rng, n_loc))  # this rank's point range: k_i * G
+        t1 = time.time()
+        res = ResidentBases(ctx, 1, bases, window_tables=True)
+        t2 = time.time()
+        del bases
+        sc = torch.from_numpy(rand_fr(rng, n_loc).view(np.int64)).to(d.dev)
+        try:
+            def run():
+                mine = np.ascontiguousarray(res.msm(device_ptr=sc.data_ptr()), dtype=np.uint64).reshape(1, 8)
+                if d.world == 1:
+                    return mine
+                t = torch.from_numpy(mine.view(np.int64))
+                t = t.to(d.dev) if d.backend == "nccl" else t
+                outs = [torch.empty_like(t) for _ in range(d.world)]
+                torch.distributed.all_gather(outs, t)
+                return outs
+            run()
+            ctx.profile(2, reset=True)
+            sec = d.timed(run, 3, warmup=0)
+            stats = ctx.kernel_stats()
+            ctx.profile(False, reset=False)
+        finally:
+            res.free()
+        return {"workload": "G1 multiexp, 2^%d points k_i*G resident as window tables, uniform scalars%s"
+                            % (log_n, "" if d.world == 1 else ", point ranges over %d GPUs, affine partial sums all-gathered" % d.world),
+                "seconds": sec, "points_per_s": n / sec, "bases_s_untimed": t1 - t0, "upload_and_tables_s_untimed": t2 - t1,
+                "roofline": accumulate_roofline(stats)}
+
+    guarded("prove_2p%d" % args.secondary_log_rows, lambda: prove_case(args.secondary_log_rows, False, 3))
+    guarded("prove_2p%d_dense" % min(args.log_rows, 20), lambda: prove_case(min(args.log_rows, 20), True, 10))
+    guarded("msm_g1_2p%d" % args.secondary_log_n, msm_standalone)
+    guarded("fr_ntt_2p%d" % args.secondary_log_n, ntt_standalone)
+    guarded("cold_start", cold_start)
+    return out
+
+
+def zinc_amd_context(device):
+    import zinc_amd
+    return zinc_amd.Context(device)
+
+
+def workload_first_proof(ctx, key, mat, zi, za, params, d):
+    """One proof from a host-resident witness on a context that has never proved (rank 0 assembles)."""
+    from zinc_amd.distributed import prove_sharded
+    from zinc_amd.fields import ints_to_mont, R_MOD
+    rs = ints_to_mont([3, 5], R_MOD)
+    return prove_sharded(ctx, key, mat, zi.ctypes.data, za.ctypes.data, 0, params.view(), rs[0], rs[1], d.rank, d.world,
+                         d.dev if d.world > 1 else None)
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as fresh child processes (before
+    this process has touched the GPU) and exit with their status."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus:  # nothing has touched the GPU yet
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run --nproc-per-node %d "
+                 "(or run `python bench.py --gpus %d` without WORLD_SIZE set)" % (args.gpus, world, args.gpus, args.gpus))
     # one rank per GPU over RCCL; ZG16_DIST_BACKEND=gloo rehearses the same code on a one-GPU box (every
     # rank on GPU 0, exchanges staged through the host)
     backend = os.environ.get("ZG16_DIST_BACKEND", "nccl")
@@ -103,45 +359,24 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     import zinc_amd
-    from zinc_amd import workload, lib as zlib
-    from zinc_amd.fields import ints_to_mont, R_MOD
-    from zinc_amd.groth16 import _check
-
+    d = Dist(rank, world, backend, local_rank)
     ctx = zinc_amd.Context(local_rank)
     ctx.graph({"auto": None, "on": True, "off": False}[args.graph])
-    L = ctx._lib
     n_rows = 1 << args.log_rows
+
+    def split_for(log_rows):
+        on = args.split_transforms == "on" or (args.split_transforms == "auto" and world >= 3 and log_rows >= 22)
+        return on and world > 1
+
     t0 = time.time()
-    circ = workload.SyntheticCircuit(n_rows, dense=args.dense)
-    params = workload.generate_parameters(ctx, circ, TOXIC)
-    r1cs = circ.r1cs()
-    key = params.upload(ctx, rank, world)
-    mat = r1cs.upload(ctx)
-    zi, za = circ.witness()
-    z_in_dev = torch.from_numpy(zi.view(np.int64)).cuda()
-    z_aux_dev = torch.from_numpy(za.view(np.int64)).cuda()
-    rs = ints_to_mont([pow(7, 123456789, R_MOD), pow(5, 987654321, R_MOD)], R_MOD)  # full-size r, s as Fr::rand gives
+    case = ProveCase(ctx, d, args.log_rows, args.dense, split_for(args.log_rows))
     setup_s = time.time() - t0
-    pk_view = params.view()
+    circ, params, r1cs, key, mat, zi, za = case.circ, case.params, case.r1cs, case.key, case.mat, case.zi, case.za
+    split = case.split
     dens = mat.density()
-
-    from zinc_amd.distributed import prove_sharded
-    dev = torch.device("cuda", local_rank) if world > 1 else None
-
-    split = args.split_transforms == "on" or (args.split_transforms == "auto" and world >= 3 and args.log_rows >= 22)
-    split = split and world > 1
-
-    def step():
-        return prove_sharded(ctx, key, mat, z_in_dev.data_ptr(), z_aux_dev.data_ptr(), 1, pk_view, rs[0], rs[1],
-                             rank, world, dev, split_transforms=split)
-
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    step, fence = case.step, d.fence
 
     for _ in range(args.warmup):
         step()
@@ -175,10 +410,8 @@ def main():
         stats_serial = ctx.kernel_stats()
         ctx.serial(False)
     ctx.profile(False, reset=False)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = d.max_over_ranks(elapsed)
+    out = None
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -189,9 +422,12 @@ def main():
                       for k, v in stats_all.items() if v[1]}
 
         pmc = {}
-        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_2p%d.json" % args.log_rows)
-        if os.path.exists(pmc_path):
-            pmc = json.load(open(pmc_path))["kernels"]
+        # the newest committed counter passes of this same command (profiles/rNN_pmc_hbm_2pK.json)
+        import glob
+        pmc_files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                                                  "r*_pmc_hbm_2p%d.json" % args.log_rows)))
+        if pmc_files:
+            pmc = json.load(open(pmc_files[-1]))["kernels"]
 
         def traffic(pmc_name, streaming):
             """HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
@@ -282,7 +518,7 @@ def main():
         }
         g1 = stats["k_accumulate<G1>"]
         if g1[0]:
-            out["msm_g1_accumulate_points_per_s"] = g1[2] / (g1[0] * 1e-3)
+            out["msm_g1_accumulate_adds_per_s"] = g1[2] / (g1[0] * 1e-3)
         if world == 1 and not args.no_cpu_baseline:
             cpu_rows = min(args.cpu_log_rows, args.log_rows)
             args.cpu_log_rows = cpu_rows
@@ -292,6 +528,13 @@ def main():
                                                            if cpu_rows == args.log_rows else None)
             out["cpu_baseline"]["sample"] = out["cpu_baseline"]["sample"].replace(
                 "(1/1 of", "(1/%d of" % (1 << (args.log_rows - args.cpu_log_rows)))
+    case.free()
+    del case, key, mat
+    if not args.no_secondary:
+        sec = secondary_block(ctx, d, args, split_for)
+        if rank == 0:
+            out["secondary"] = sec
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

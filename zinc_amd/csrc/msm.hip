@@ -1164,6 +1164,7 @@ static zg16_status msm_blocking(zg16_ctx* ctx, int slot, const MsmJob<F>* jobs, 
   MsmStreams ms = {ctx->stream, nullptr, nullptr, nullptr};
   ZG_TRY(msm_launch<F>(ctx, ms, slot, ctx->pinned, jobs, njobs, 1, &pend));
   ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  profile_collect(ctx);
   return msm_collect<F>(ctx, &pend, out_host);
 }
 
