@@ -26,6 +26,7 @@ struct PassParams {
   uint32_t in_hi, in_lo, out_hi, out_lo, tw_lo_mul;
   uint32_t tw_scale;  // inter-pass twiddle exponent scale (k_pass_twiddles), 0: none
   uint32_t load_j_fast;
+  uint32_t nq;  // non-zero: logical tile L splits as q = L % nq, rem = L / nq (q fastest) instead of by bdiv
 };
 
 // N = R1*R2*R3: the passes of one transform and their launch sizes
@@ -91,6 +92,13 @@ ZG_D void lds_put(uint32_t* s, uint32_t i, const Fr29& x) {
   for (int k = 0; k < 9; k++) e[k] = x.v[k];
 }
 
+// Workgroups go to the eight XCDs round-robin (workgroup b runs on XCD b mod 8) and every XCD has its own L2.  A
+// tile narrower than a 128-byte line (four elements) shares its lines with the tiles next to it, so tiles that are
+// neighbours in memory are given to the same XCD at about the same time: XCD x works through the contiguous run of
+// logical tiles [x G/8, (x+1) G/8).  The partial lines then meet in that L2 instead of being fetched from (and
+// written back to) HBM once per tile.
+ZG_D uint32_t xcd_tile(uint32_t b, uint32_t grid) { return (grid & 7) ? b : (b & 7) * (grid >> 3) + (b >> 3); }
+
 // One decimation-in-time butterfly on lazy values: (x0, x1) <- (x0 + t, x0 - t) with t = x1 * w, or
 // t = x1 when the twiddle is one (TRIVIAL).  The subtrahend is a fresh product (below 2p) or, in the
 // trivial case, a value below `KSUB` p, so the result grows by an additive constant per stage instead
@@ -127,7 +135,8 @@ __global__ __launch_bounds__(256, 4) void k_ntt_pass(const Fr* __restrict__ in, 
   const uint32_t tid = threadIdx.x;
   const uint32_t logR = p.logR, logT = p.logT;
   const uint32_t R = 1u << logR, T = 1u << logT, E = R << logT;
-  const uint32_t q = blockIdx.x / p.bdiv, rem = blockIdx.x % p.bdiv;
+  const uint32_t tile = xcd_tile(blockIdx.x, gridDim.x);
+  const uint32_t q = p.nq ? tile % p.nq : tile / p.bdiv, rem = p.nq ? tile / p.nq : tile % p.bdiv;
   const uint32_t in_base = q * p.in_hi + rem * p.in_lo;
   const uint32_t out_base = q * p.out_hi + rem * p.out_lo;
   const uint32_t wshift = MAX_RADIX_BITS - logR;  // w_R^e = w_1024^(e << wshift)
@@ -324,6 +333,7 @@ static NttPlan make_plan(unsigned n) {
     p.out_lo = R1;
     p.tw_scale = 0;
     p.load_j_fast = 1;
+    p.nq = R1 >> p.logT;  // tiles of adjacent k1 are neighbours in the output
     pl.grid_c = (R1 >> p.logT) * R2;
   }
   return pl;
