@@ -131,6 +131,45 @@ void        zg16_r1cs_free(zg16_r1cs* r1cs);
 /* popcounts of the density maps: a_aux, b_input, b_aux (any pointer may be NULL). */
 zg16_status zg16_r1cs_density(const zg16_r1cs* r1cs, size_t* a_aux, size_t* b_input, size_t* b_aux);
 
+/* ---- resident keys and circuits between calls ----------------------------------------------
+ * The reference's callers cannot hold a device handle: `zvm prove` reads the key and proves once per process
+ * (zinc-vm/src/zvm/arguments/command/prove.rs:73-88) and zinc-tester proves every case with `params.clone()`
+ * (zinc-tester/src/runners/proof_check.rs:122, :181).  A drop-in `create_random_proof` therefore asks the library
+ * for what it has already uploaded; expanding a key into window tables costs about a hundred proofs.
+ *
+ * zg16_default_ctx: one context per GPU, created on first use, alive until zg16_shutdown or the end of the process
+ * (do not pass it to zg16_ctx_destroy while others may still ask for it).
+ * zg16_pk_cached: the resident handle of the key `view` shows, uploaded (unsharded) on first sight.  A key is
+ * recognised by its vector lengths, its verifying-key points and 1024 evenly spaced points of every query; with
+ * `full_digest` every point is read instead.  *was_cached (may be NULL) tells whether the upload was skipped.
+ * zg16_r1cs_cached: the same for constraint matrices.  The structure of a circuit does not depend on its inputs,
+ * so a caller that can name it -- `circuit_id`, any bytes, e.g. a digest of the bytecode and the method name
+ * (the synthesis-side cost: zinc-vm/src/constraint_systems/dedup.rs:30-69, logging.rs:99-111) -- calls with
+ * view = NULL first: a known circuit comes back at once and the caller synthesizes with a constraint system that
+ * records only the witness; *out = NULL with ZG16_OK means unknown, record the matrices and call again with the
+ * view.  With circuit_id = NULL the matrices themselves are digested (every byte).
+ * Handles returned here belong to the context: zg16_pk_free / zg16_r1cs_free ignore them; they are released by
+ * zg16_cache_clear, by zg16_ctx_destroy, or when newer entries push them out (least recently used first; at most
+ * ZG16_CACHE_KEYS keys, default 4, and ZG16_CACHE_CIRCUITS circuits, default 16, per context; a key that does not
+ * fit beside the cached ones evicts them).  A key handle stays valid at least until the next zg16_pk_cached call
+ * on its context, a circuit handle until the next zg16_r1cs_cached call. */
+zg16_status zg16_default_ctx(int device_id, zg16_ctx** out);
+void        zg16_shutdown(void);
+zg16_status zg16_pk_cached(zg16_ctx* ctx, const zg16_pk_view* view, int full_digest, zg16_pk** out,
+                           int* was_cached);
+/* 1 when `pk` is a key handle this context's cache still holds (and marks it used), else 0: lets a host that
+ * remembers which of its key objects maps to which handle skip building a view for zg16_pk_cached. */
+int         zg16_pk_cache_holds(zg16_ctx* ctx, const zg16_pk* pk);
+zg16_status zg16_r1cs_cached(zg16_ctx* ctx, const uint8_t* circuit_id, size_t circuit_id_len,
+                             const zg16_r1cs_view* view, zg16_r1cs** out, int* was_cached);
+zg16_status zg16_cache_clear(zg16_ctx* ctx);
+typedef struct {
+  uint64_t keys, circuits;               /* entries held now          */
+  uint64_t key_hits, key_misses, circuit_hits, circuit_misses, evictions;
+  uint64_t key_bytes;                    /* HBM held by cached keys   */
+} zg16_cache_counts;
+zg16_status zg16_cache_stats(const zg16_ctx* ctx, zg16_cache_counts* out);
+
 /* ---- prove -------------------------------------------------------------------------------- */
 /* bellman `create_proof(circuit, params, r, s)`: z_in has n_inputs elements (z_in[0] = ONE),
  * z_aux has n_aux elements, r and s are Montgomery Fr.  Witness pointers are host memory unless

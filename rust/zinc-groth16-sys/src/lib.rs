@@ -7,7 +7,7 @@
 //! 4 little-endian u64 Montgomery limbs, which is the ABI's element layout.
 #![allow(non_camel_case_types)]
 use franklin_crypto::bellman::groth16::{Parameters, Proof};
-use franklin_crypto::bellman::pairing::bn256::{Bn256, Fr, G1Affine, G2Affine};
+use franklin_crypto::bellman::pairing::bn256::{Bn256, Fq, Fq2, Fr, G1Affine, G2Affine};
 use franklin_crypto::bellman::pairing::ff::{Field, PrimeField};
 use franklin_crypto::bellman::pairing::CurveAffine;
 use franklin_crypto::bellman::{Circuit, ConstraintSystem, Index, LinearCombination, SynthesisError, Variable};
@@ -53,6 +53,13 @@ extern "C" {
                                  r: *const u64, s: *const u64, out: *mut zg16_proof) -> c_int;
     /// bellman `Proof::write` (the 128 bytes `zvm prove` prints as hex, prove.rs:171-174).
     pub fn zg16_proof_encode(proof: *const zg16_proof, out: *mut u8) -> c_int;
+    /// The process-wide context of a GPU and its cache of resident keys / circuits: what lets a caller that
+    /// cannot keep a handle (prove.rs:73-88, zinc-tester proof_check.rs:122) pay for the key upload once.
+    pub fn zg16_default_ctx(device_id: c_int, out: *mut *mut zg16_ctx) -> c_int;
+    pub fn zg16_pk_cached(ctx: *mut zg16_ctx, view: *const zg16_pk_view, full_digest: c_int, out: *mut *mut zg16_pk, was_cached: *mut c_int) -> c_int;
+    pub fn zg16_pk_cache_holds(ctx: *mut zg16_ctx, pk: *const zg16_pk) -> c_int;
+    pub fn zg16_r1cs_cached(ctx: *mut zg16_ctx, circuit_id: *const u8, circuit_id_len: usize, view: *const zg16_r1cs_view,
+                            out: *mut *mut zg16_r1cs, was_cached: *mut c_int) -> c_int;
 }
 
 /// Plays the role of bellman's `ProvingAssignment`, but records the matrices instead of evaluating
@@ -61,11 +68,15 @@ extern "C" {
 pub struct RecordingAssignment {
     pub z_in: Vec<Fr>, pub z_aux: Vec<Fr>,
     row_ptr: [Vec<u64>; 3], col: [Vec<u32>; 3], coeff: [Vec<Fr>; 3],
+    /// The circuit's matrices are already resident on the GPU: `enforce` returns without calling its closures, so
+    /// no LinearCombination is built and synthesis pays for witness generation only.
+    witness_only: bool,
 }
 
 impl RecordingAssignment {
-    pub fn new() -> Self {
-        RecordingAssignment { z_in: vec![], z_aux: vec![], row_ptr: [vec![0], vec![0], vec![0]], col: Default::default(), coeff: Default::default() }
+    pub fn new() -> Self { Self::with_mode(false) }
+    pub fn with_mode(witness_only: bool) -> Self {
+        RecordingAssignment { z_in: vec![], z_aux: vec![], row_ptr: [vec![0], vec![0], vec![0]], col: Default::default(), coeff: Default::default(), witness_only }
     }
     fn push(&mut self, k: usize, lc: &LinearCombination<Bn256>) {
         for (var, coeff) in lc.as_ref() {
@@ -94,6 +105,7 @@ impl ConstraintSystem<Bn256> for RecordingAssignment {
           LA: FnOnce(LinearCombination<Bn256>) -> LinearCombination<Bn256>,
           LB: FnOnce(LinearCombination<Bn256>) -> LinearCombination<Bn256>,
           LC: FnOnce(LinearCombination<Bn256>) -> LinearCombination<Bn256> {
+        if self.witness_only { return; }
         let (a, b, c) = (a(LinearCombination::zero()), b(LinearCombination::zero()), c(LinearCombination::zero()));
         self.push(0, &a); self.push(1, &b); self.push(2, &c);
     }
@@ -115,13 +127,26 @@ fn status_to_error(st: c_int) -> SynthesisError {
     }
 }
 
-/// Same signature shape and semantics as bellman's `create_proof`.
-pub fn create_proof<C: Circuit<Bn256>>(circuit: C, params: &Parameters<Bn256>, r: Fr, s: Fr) -> Result<Proof<Bn256>, SynthesisError> {
-    let mut cs = RecordingAssignment::new();
-    cs.alloc_input(|| "", || Ok(Fr::one()))?;
-    circuit.synthesize(&mut cs)?;
-    for i in 0..cs.z_in.len() {
-        cs.enforce(|| "", |lc| lc + Variable::new_unchecked(Index::Input(i)), |lc| lc, |lc| lc);
+/// Host-side memo of converted keys: `Parameters<Bn256>` keeps its vectors behind `Arc`s, so `params.clone()`
+/// (zinc-tester/src/runners/proof_check.rs:122) shares them and the `Arc` addresses identify the key.  The entry
+/// holds clones of the `Arc`s, which keeps those addresses from being reused while it is cached.
+struct KeyMemo {
+    h: std::sync::Arc<Vec<G1Affine>>, l: std::sync::Arc<Vec<G1Affine>>, a: std::sync::Arc<Vec<G1Affine>>,
+    b_g1: std::sync::Arc<Vec<G1Affine>>, b_g2: std::sync::Arc<Vec<G2Affine>>,
+    pk: usize, // *mut zg16_pk owned by the library's cache
+}
+thread_local! { static KEY_MEMO: std::cell::RefCell<Vec<KeyMemo>> = std::cell::RefCell::new(Vec::new()); }
+
+/// The resident handle of `params` on `ctx`: converted and handed to `zg16_pk_cached` the first time this set of
+/// `Arc`s is seen, looked up by address afterwards (no conversion, no upload).
+unsafe fn resident_key(ctx: *mut zg16_ctx, params: &Parameters<Bn256>) -> Result<*mut zg16_pk, c_int> {
+    use std::sync::Arc;
+    let known = KEY_MEMO.with(|m| m.borrow().iter().find(|e|
+        Arc::ptr_eq(&e.h, &params.h) && Arc::ptr_eq(&e.l, &params.l) && Arc::ptr_eq(&e.a, &params.a) &&
+        Arc::ptr_eq(&e.b_g1, &params.b_g1) && Arc::ptr_eq(&e.b_g2, &params.b_g2)).map(|e| e.pk));
+    if let Some(pk) = known {
+        // the library may have evicted the key since; only a handle it still holds is used without a view
+        if zg16_pk_cache_holds(ctx, pk as *const zg16_pk) != 0 { return Ok(pk as *mut zg16_pk); }
     }
     let conv1 = |v: &Vec<G1Affine>| v.iter().map(g1).collect::<Vec<_>>();
     let (h, l, a, b1) = (conv1(&params.h), conv1(&params.l), conv1(&params.a), conv1(&params.b_g1));
@@ -131,25 +156,63 @@ pub fn create_proof<C: Circuit<Bn256>>(circuit: C, params: &Parameters<Bn256>, r
     let pkv = zg16_pk_view { alpha_g1: al.as_ptr(), beta_g1: be1.as_ptr(), beta_g2: be2.as_ptr(), delta_g1: de1.as_ptr(), delta_g2: de2.as_ptr(),
         h: h.as_ptr() as *const u64, n_h: h.len(), l: l.as_ptr() as *const u64, n_l: l.len(), a: a.as_ptr() as *const u64, n_a: a.len(),
         b_g1: b1.as_ptr() as *const u64, n_b_g1: b1.len(), b_g2: b2.as_ptr() as *const u64, n_b_g2: b2.len() };
-    let csr = |k: usize| zg16_csr { row_ptr: cs.row_ptr[k].as_ptr(), col: cs.col[k].as_ptr(), coeff: cs.coeff[k].as_ptr() as *const u64 };
-    let rv = zg16_r1cs_view { n_rows: cs.row_ptr[0].len() - 1, n_inputs: cs.z_in.len(), n_aux: cs.z_aux.len(), a: csr(0), b: csr(1), c: csr(2) };
+    let mut pk = std::ptr::null_mut();
+    let mut hit: c_int = 0;
+    let st = zg16_pk_cached(ctx, &pkv, 0, &mut pk, &mut hit);
+    if st != 0 { return Err(st); }
+    KEY_MEMO.with(|m| {
+        let mut m = m.borrow_mut();
+        m.retain(|e| e.pk != pk as usize);
+        m.push(KeyMemo { h: params.h.clone(), l: params.l.clone(), a: params.a.clone(), b_g1: params.b_g1.clone(), b_g2: params.b_g2.clone(), pk: pk as usize });
+        if m.len() > 4 { m.remove(0); }
+    });
+    Ok(pk)
+}
+
+/// Same signature shape and semantics as bellman's `create_proof`, plus `circuit_id`: bytes that name the circuit
+/// (e.g. a digest of the bytecode and the method name; its structure does not depend on the inputs).  Once the
+/// library holds the matrices of a named circuit, synthesis runs in witness-only mode.
+pub fn create_proof_named<C: Circuit<Bn256>>(circuit: C, params: &Parameters<Bn256>, r: Fr, s: Fr, circuit_id: Option<&[u8]>) -> Result<Proof<Bn256>, SynthesisError> {
     unsafe {
-        let (mut ctx, mut pk, mut mat) = (std::ptr::null_mut(), std::ptr::null_mut(), std::ptr::null_mut());
-        let mut out = std::mem::zeroed::<zg16_proof>();
-        let mut st = zg16_ctx_create(0, &mut ctx);
-        if st == 0 { st = zg16_pk_upload(ctx, &pkv, 0, 1, &mut pk); }
-        if st == 0 { st = zg16_r1cs_upload(ctx, &rv, &mut mat); }
-        if st == 0 {
-            st = zg16_prove(ctx, pk, mat, cs.z_in.as_ptr() as *const c_void, cs.z_aux.as_ptr() as *const c_void, 0,
-                            &r as *const Fr as *const u64, &s as *const Fr as *const u64, &mut out);
-        }
-        zg16_r1cs_free(mat); zg16_pk_free(pk); zg16_ctx_destroy(ctx);
+        let mut ctx = std::ptr::null_mut();
+        let st = zg16_default_ctx(0, &mut ctx);
         if st != 0 { return Err(status_to_error(st)); }
-        // coordinates are Montgomery limbs in ff_ce's own layout, so the reinterpretation below is exact
-        Ok(Proof { a: G1Affine::from_xy_unchecked(std::mem::transmute_copy(&out.a[0..4]), std::mem::transmute_copy(&out.a[4..8])),
-                   b: G2Affine::from_xy_unchecked(std::mem::transmute_copy(&out.b[0..8]), std::mem::transmute_copy(&out.b[8..16])),
-                   c: G1Affine::from_xy_unchecked(std::mem::transmute_copy(&out.c[0..4]), std::mem::transmute_copy(&out.c[4..8])) })
+        let mut mat: *mut zg16_r1cs = std::ptr::null_mut();
+        let mut hit: c_int = 0;
+        if let Some(id) = circuit_id {
+            let st = zg16_r1cs_cached(ctx, id.as_ptr(), id.len(), std::ptr::null(), &mut mat, &mut hit);
+            if st != 0 { return Err(status_to_error(st)); }
+        }
+        let mut cs = RecordingAssignment::with_mode(!mat.is_null());
+        cs.alloc_input(|| "", || Ok(Fr::one()))?;
+        circuit.synthesize(&mut cs)?;
+        for i in 0..cs.z_in.len() {
+            cs.enforce(|| "", |lc| lc + Variable::new_unchecked(Index::Input(i)), |lc| lc, |lc| lc);
+        }
+        let pk = resident_key(ctx, params).map_err(status_to_error)?;
+        if mat.is_null() {
+            let csr = |k: usize| zg16_csr { row_ptr: cs.row_ptr[k].as_ptr(), col: cs.col[k].as_ptr(), coeff: cs.coeff[k].as_ptr() as *const u64 };
+            let rv = zg16_r1cs_view { n_rows: cs.row_ptr[0].len() - 1, n_inputs: cs.z_in.len(), n_aux: cs.z_aux.len(), a: csr(0), b: csr(1), c: csr(2) };
+            let (idp, idl) = match circuit_id { Some(id) => (id.as_ptr(), id.len()), None => (std::ptr::null(), 0) };
+            let st = zg16_r1cs_cached(ctx, idp, idl, &rv, &mut mat, &mut hit);
+            if st != 0 { return Err(status_to_error(st)); }
+        }
+        let mut out = std::mem::zeroed::<zg16_proof>();
+        let st = zg16_prove(ctx, pk, mat, cs.z_in.as_ptr() as *const c_void, cs.z_aux.as_ptr() as *const c_void, 0,
+                            &r as *const Fr as *const u64, &s as *const Fr as *const u64, &mut out);
+        if st != 0 { return Err(status_to_error(st)); }
+        // Coordinates are Montgomery limbs in ff_ce's own layout (`Fq` is four u64, `Fq2` is { c0, c1 }), so the
+        // sized reinterpretations below are exact: [u64; 8] = [Fq; 2] = (x, y), [u64; 16] = [Fq2; 2].
+        let [ax, ay]: [Fq; 2] = std::mem::transmute(out.a);
+        let [bx, by]: [Fq2; 2] = std::mem::transmute(out.b);
+        let [cx, cy]: [Fq; 2] = std::mem::transmute(out.c);
+        Ok(Proof { a: G1Affine::from_xy_unchecked(ax, ay), b: G2Affine::from_xy_unchecked(bx, by), c: G1Affine::from_xy_unchecked(cx, cy) })
     }
+}
+
+/// bellman's `create_proof(circuit, params, r, s)`.
+pub fn create_proof<C: Circuit<Bn256>>(circuit: C, params: &Parameters<Bn256>, r: Fr, s: Fr) -> Result<Proof<Bn256>, SynthesisError> {
+    create_proof_named(circuit, params, r, s, None)
 }
 
 /// Drop-in for `groth16::create_random_proof` (r first, then s, both `rng.gen::<Fr>()`).

@@ -73,6 +73,20 @@ int main(int argc, char** argv) {
     } catch (const SynthesisError& e) {
       if (e.status != ZG16_ERR_UNEXPECTED_IDENTITY) { fprintf(stderr, "wrong error: %s\n", e.variant()); return 1; }
     }
+    // the resident path a zinc-tester-style loop takes: the key and the circuit are uploaded by the first call only
+    for (int round = 0; round < 3; round++) {
+      Proof again = create_proof(c, p, r, s, std::string("fixture/main"));
+      if (memcmp(&again, &want, sizeof again) != 0) { fprintf(stderr, "cached proof %d differs from the fixture\n", round); return 1; }
+    }
+    zg16_cache_counts cc;
+    if (zg16_cache_stats(Prover::shared().ctx(), &cc) != ZG16_OK || cc.key_misses != 1 || cc.key_hits != 2 ||
+        cc.circuit_misses != 1 || cc.circuit_hits != 2 || cc.keys != 1 || cc.circuits != 1) {
+      fprintf(stderr, "cache counts: keys %llu (%llu hits, %llu misses), circuits %llu (%llu hits, %llu misses)\n",
+              (unsigned long long)cc.keys, (unsigned long long)cc.key_hits, (unsigned long long)cc.key_misses,
+              (unsigned long long)cc.circuits, (unsigned long long)cc.circuit_hits, (unsigned long long)cc.circuit_misses);
+      return 1;
+    }
+    zg16_shutdown();
   } catch (const SynthesisError& e) {
     fprintf(stderr, "SynthesisError::%s: %s\n", e.variant(), e.what());
     return 1;

@@ -59,12 +59,13 @@ constexpr uint32_t AUX_BIT = 0x80000000u;
 // Upload `count` points as window 0 of a table of `windows` windows and fill the other windows.
 template <class F>
 zg16_status upload_query(zg16_ctx* ctx, Affine<F>** dst, const void* src, size_t count, uint32_t table_c,
-                         Affine<F>** direct) {
+                         Affine<F>** direct, size_t* device_bytes = nullptr) {
   *dst = nullptr;
   *direct = nullptr;
   if (!count) return ZG16_OK;
   const size_t windows = table_c ? msm_table_windows(table_c) : 1;
   ZG_HIP(ctx, hipMalloc((void**)dst, windows * count * sizeof(Affine<F>)));
+  if (device_bytes) *device_bytes += windows * count * sizeof(Affine<F>);
   ZG_HIP(ctx, hipMemcpy(*dst, src, count * sizeof(Affine<F>), hipMemcpyHostToDevice));
   // small queries also get a direct table of every multiple a digit can ask for (built from the ABI-form points)
   if (table_c) ZG_TRY(msm_build_direct<F>(ctx, *dst, count, direct));
@@ -190,8 +191,10 @@ zg16_status zg16_ctx_create(int device_id, zg16_ctx** out) {
 
 void zg16_ctx_destroy(zg16_ctx* ctx) {
   if (!ctx) return;
+  default_ctx_forget(ctx);
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
+  cache_free(ctx);
   drop_graphs(ctx, nullptr);
   ntt_free_domains(ctx);
   ntt_free_cross_tables(ctx);
@@ -226,7 +229,7 @@ zg16_status zg16_pk_upload(zg16_ctx* ctx, const zg16_pk_view* v, int shard_index
   if ((v->n_h && !v->h) || (v->n_l && !v->l) || (v->n_a && !v->a) || (v->n_b_g1 && !v->b_g1) || (v->n_b_g2 && !v->b_g2))
     return fail(ctx, ZG16_ERR_MALFORMED_KEY, "a query vector has a length but no points");
   ZG_HIP(ctx, hipSetDevice(ctx->device));
-  std::unique_ptr<zg16_pk, void (*)(zg16_pk*)> pk(new zg16_pk(), zg16_pk_free);
+  std::unique_ptr<zg16_pk, void (*)(zg16_pk*)> pk(new zg16_pk(), zg::pk_destroy);
   pk->ctx = ctx;
   pk->shard_index = shard_index;
   pk->shard_count = shard_count;
@@ -241,11 +244,11 @@ zg16_status zg16_pk_upload(zg16_ctx* ctx, const zg16_pk_view* v, int shard_index
   pk->table_c = msm_table_window(largest, 1);
   pk->table_c_h = msm_table_window(pk->hi_h - pk->lo_h, 0);
   pk->table_c_g2 = msm_table_window(pk->hi_b - pk->lo_b, 2);
-  ZG_TRY(upload_query<Fq>(ctx, &pk->h, v->h + 8 * pk->lo_h, pk->hi_h - pk->lo_h, pk->table_c_h, &pk->h_d));
-  ZG_TRY(upload_query<Fq>(ctx, &pk->l, v->l + 8 * pk->lo_l, pk->hi_l - pk->lo_l, pk->table_c, &pk->l_d));
-  ZG_TRY(upload_query<Fq>(ctx, &pk->a, v->a + 8 * pk->lo_a, pk->hi_a - pk->lo_a, pk->table_c, &pk->a_d));
-  ZG_TRY(upload_query<Fq>(ctx, &pk->b1, v->b_g1 + 8 * pk->lo_b, pk->hi_b - pk->lo_b, pk->table_c, &pk->b1_d));
-  ZG_TRY(upload_query<Fq2>(ctx, &pk->b2, v->b_g2 + 16 * pk->lo_b, pk->hi_b - pk->lo_b, pk->table_c_g2, &pk->b2_d));
+  ZG_TRY(upload_query<Fq>(ctx, &pk->h, v->h + 8 * pk->lo_h, pk->hi_h - pk->lo_h, pk->table_c_h, &pk->h_d, &pk->device_bytes));
+  ZG_TRY(upload_query<Fq>(ctx, &pk->l, v->l + 8 * pk->lo_l, pk->hi_l - pk->lo_l, pk->table_c, &pk->l_d, &pk->device_bytes));
+  ZG_TRY(upload_query<Fq>(ctx, &pk->a, v->a + 8 * pk->lo_a, pk->hi_a - pk->lo_a, pk->table_c, &pk->a_d, &pk->device_bytes));
+  ZG_TRY(upload_query<Fq>(ctx, &pk->b1, v->b_g1 + 8 * pk->lo_b, pk->hi_b - pk->lo_b, pk->table_c, &pk->b1_d, &pk->device_bytes));
+  ZG_TRY(upload_query<Fq2>(ctx, &pk->b2, v->b_g2 + 16 * pk->lo_b, pk->hi_b - pk->lo_b, pk->table_c_g2, &pk->b2_d, &pk->device_bytes));
   memcpy(&pk->alpha_g1, v->alpha_g1, 64);
   memcpy(&pk->beta_g1, v->beta_g1, 64);
   memcpy(&pk->delta_g1, v->delta_g1, 64);
@@ -257,6 +260,12 @@ zg16_status zg16_pk_upload(zg16_ctx* ctx, const zg16_pk_view* v, int shard_index
 }
 
 void zg16_pk_free(zg16_pk* pk) {
+  if (!pk || pk->cached) return;  // a cached key belongs to its context (zg16_cache_clear / zg16_ctx_destroy)
+  zg::pk_destroy(pk);
+}
+}  // extern "C"
+
+void zg::pk_destroy(zg16_pk* pk) {
   if (!pk) return;
   if (pk->ctx) {
     (void)hipSetDevice(pk->ctx->device);
@@ -266,6 +275,8 @@ void zg16_pk_free(zg16_pk* pk) {
   (void)hipFree(pk->h_d); (void)hipFree(pk->l_d); (void)hipFree(pk->a_d); (void)hipFree(pk->b1_d); (void)hipFree(pk->b2_d);
   delete pk;
 }
+
+extern "C" {
 
 // --------------------------------------------------------------------------- constraint matrices
 zg16_status zg16_r1cs_upload(zg16_ctx* ctx, const zg16_r1cs_view* v, zg16_r1cs** out) {
@@ -278,7 +289,7 @@ zg16_status zg16_r1cs_upload(zg16_ctx* ctx, const zg16_r1cs_view* v, zg16_r1cs**
   // bellman's EvaluationDomain::from_coeffs gives up once the exponent reaches Fr's two-adicity
   if (log_m >= 28) return fail(ctx, ZG16_ERR_POLYNOMIAL_DEGREE_TOO_LARGE, "%zu rows need a domain of 2^%u", v->n_rows, log_m);
   ZG_HIP(ctx, hipSetDevice(ctx->device));
-  std::unique_ptr<zg16_r1cs, void (*)(zg16_r1cs*)> r(new zg16_r1cs(), zg16_r1cs_free);
+  std::unique_ptr<zg16_r1cs, void (*)(zg16_r1cs*)> r(new zg16_r1cs(), zg::r1cs_destroy);
   r->ctx = ctx;
   r->n_rows = v->n_rows; r->n_in = v->n_inputs; r->n_aux = v->n_aux; r->log_m = log_m;
   const zg16_csr* mats[3] = {&v->a, &v->b, &v->c};
@@ -337,6 +348,12 @@ zg16_status zg16_r1cs_upload(zg16_ctx* ctx, const zg16_r1cs_view* v, zg16_r1cs**
 }
 
 void zg16_r1cs_free(zg16_r1cs* r) {
+  if (!r || r->cached) return;  // a cached circuit belongs to its context
+  zg::r1cs_destroy(r);
+}
+}  // extern "C"
+
+void zg::r1cs_destroy(zg16_r1cs* r) {
   if (!r) return;
   if (r->ctx) {
     (void)hipSetDevice(r->ctx->device);
@@ -348,6 +365,8 @@ void zg16_r1cs_free(zg16_r1cs* r) {
   (void)hipFree(r->a_map); (void)hipFree(r->b_map);
   delete r;
 }
+
+extern "C" {
 
 zg16_status zg16_r1cs_density(const zg16_r1cs* r, size_t* a_aux, size_t* b_input, size_t* b_aux) {
   if (!r) return ZG16_ERR_INVALID_ARGUMENT;

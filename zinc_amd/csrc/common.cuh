@@ -15,6 +15,7 @@ namespace zg {
 
 struct NttDomain;   // ntt.hip
 struct ProveGraph;  // api.hip: a captured proof (hipGraphExec_t and what the host needs to read its results)
+struct HandleCache; // cache.hip: keys and matrices the context keeps resident between proofs
 
 }  // namespace zg
 
@@ -65,6 +66,7 @@ struct zg16_ctx {
   void* scratch[10] = {};
   size_t scratch_bytes[10] = {};
   zg16_timings timings = {};
+  zg::HandleCache* cache = nullptr;  // created on first use (zg16_pk_cached / zg16_r1cs_cached)
 };
 
 namespace zg {
@@ -248,6 +250,8 @@ zg16_status msm_collect(zg16_ctx* ctx, const MsmPending* pend, XYZZ<F>* out);
 // context's device must be current).
 zg16_status msm_noalloc_init(zg16_ctx* ctx);
 
+void cache_free(zg16_ctx* ctx);  // cache.hip: releases every cached handle (the context is going away)
+void default_ctx_forget(zg16_ctx* ctx);  // cache.hip: zg16_default_ctx stops handing this context out
 void ntt_free_domains(zg16_ctx* ctx);
 void ntt_free_cross_tables(zg16_ctx* ctx);
 // The cross-GPU step of a 2^log_n-point transform sharded over 2^log_g GPUs (see ntt.hip), in place on

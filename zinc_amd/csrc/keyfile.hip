@@ -184,7 +184,7 @@ zg16_status zg16_pk_upload_bytes(zg16_ctx* ctx, const uint8_t* data, size_t len,
   const Fq2 curve_b = g2_curve_b();
   Cursor cur = {data, len};
   auto eof = [&]() { return fail(ctx, ZG16_ERR_MALFORMED_KEY, "unexpected end of key data"); };
-  std::unique_ptr<zg16_pk, void (*)(zg16_pk*)> pk(new zg16_pk(), zg16_pk_free);
+  std::unique_ptr<zg16_pk, void (*)(zg16_pk*)> pk(new zg16_pk(), zg::pk_destroy);
   pk->ctx = ctx;
   pk->shard_index = shard_index;
   pk->shard_count = shard_count;

@@ -26,6 +26,7 @@ zg16_status spmv_one_device(zg16_ctx* ctx, const zg16_r1cs* r, int k, const Fr* 
 
 struct zg16_r1cs {
   zg16_ctx* ctx = nullptr;
+  bool cached = false;  // owned by the context's cache: zg16_r1cs_free leaves it alone
   size_t n_rows = 0, n_in = 0, n_aux = 0;
   unsigned log_m = 0;
   zg::R1csMatrix m[3];
@@ -39,6 +40,8 @@ struct zg16_r1cs {
 
 struct zg16_pk {
   zg16_ctx* ctx = nullptr;
+  bool cached = false;  // owned by the context's cache: zg16_pk_free leaves it alone
+  size_t device_bytes = 0;  // HBM held by the query tables
   int shard_index = 0, shard_count = 1;
   // totals of the full key and the [lo, hi) range this shard holds, per query
   size_t n_h = 0, n_l = 0, n_a = 0, n_b1 = 0, n_b2 = 0;
@@ -67,6 +70,12 @@ struct zg16_pk {
     delta2_table->build(delta_g2);
   }
 };
+
+namespace zg {
+// Release a handle whoever owns it (zg16_pk_free / zg16_r1cs_free skip handles the cache owns).
+void pk_destroy(zg16_pk* pk);
+void r1cs_destroy(zg16_r1cs* r);
+}  // namespace zg
 
 // A base set resident in HBM (zg16_bases_upload): `n` points, optionally as a window table.
 struct zg16_bases {

@@ -32,18 +32,34 @@ def _check(ctx_handle, status):
 class Context:
     """One GPU: streams, scratch memory, cached NTT tables."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, _default=False):
         self._lib = _lib.load()
         self.handle = C.c_void_p()
-        st = self._lib.zg16_ctx_create(device, C.byref(self.handle))
+        create = self._lib.zg16_default_ctx if _default else self._lib.zg16_ctx_create
+        st = create(device, C.byref(self.handle))
         if st != _lib.OK:
             raise SynthesisError(st, "cannot create a context on GPU %d (is an MI355X visible?)" % device)
         self.device = device
+        self._owned = not _default
+
+    @classmethod
+    def default(cls, device=0):
+        """zg16_default_ctx: the process-wide context of a GPU (created on first use, never closed by this
+        object), whose cache keeps keys and circuits resident between create_proof calls."""
+        return cls(device, _default=True)
 
     def close(self):
-        if self.handle:
+        if self.handle and self._owned:
             self._lib.zg16_ctx_destroy(self.handle)
-            self.handle = C.c_void_p()
+        self.handle = C.c_void_p()
+
+    def cache_stats(self):
+        c = _lib.CacheCounts()
+        _check(self.handle, self._lib.zg16_cache_stats(self.handle, C.byref(c)))
+        return {n: getattr(c, n) for n, _ in c._fields_}
+
+    def cache_clear(self):
+        _check(self.handle, self._lib.zg16_cache_clear(self.handle))
 
     def __del__(self):
         try:
@@ -217,6 +233,17 @@ class Parameters:
     def upload(self, ctx, shard_index=0, shard_count=1):
         return DeviceKey(ctx, self, shard_index, shard_count)
 
+    def cached(self, ctx, full_digest=False):
+        """zg16_pk_cached: the context's resident handle of this key (uploaded on first sight); returns
+        (DeviceKey, was_cached).  The handle belongs to the context; free() on it does nothing."""
+        key = DeviceKey(ctx, None)
+        key.params = self
+        v, hit = self.view(), C.c_int()
+        _check(ctx.handle, ctx._lib.zg16_pk_cached(ctx.handle, C.byref(v), int(full_digest), C.byref(key.handle),
+                                                   C.byref(hit)))
+        key._borrowed = True
+        return key, bool(hit.value)
+
 
 class DeviceKey:
     def __init__(self, ctx, params, shard_index=0, shard_count=1):
@@ -243,9 +270,9 @@ class DeviceKey:
         return v
 
     def free(self):
-        if self.handle:
+        if self.handle and not getattr(self, "_borrowed", False):
             self.ctx._lib.zg16_pk_free(self.handle)
-            self.handle = C.c_void_p()
+        self.handle = C.c_void_p()
 
     def __del__(self):
         try:
@@ -278,13 +305,36 @@ class R1CS:
     def upload(self, ctx):
         return DeviceR1CS(ctx, self)
 
+    def cached(self, ctx, circuit_id=None):
+        """zg16_r1cs_cached with the matrices in hand: returns (DeviceR1CS, was_cached)."""
+        return DeviceR1CS.cached(ctx, circuit_id, self)
+
 
 class DeviceR1CS:
     def __init__(self, ctx, r1cs):
         self.ctx, self.r1cs = ctx, r1cs
         self.handle = C.c_void_p()
+        if r1cs is None:
+            return
         v = r1cs.view()
         _check(ctx.handle, ctx._lib.zg16_r1cs_upload(ctx.handle, C.byref(v), C.byref(self.handle)))
+
+    @classmethod
+    def cached(cls, ctx, circuit_id, r1cs=None):
+        """zg16_r1cs_cached.  circuit_id: bytes naming the circuit (e.g. a digest of bytecode + method), or None to
+        have the matrices digested.  r1cs None: look-up only; returns (None, False) for an unknown circuit."""
+        self = cls(ctx, None)
+        self.r1cs = r1cs
+        self._borrowed = True
+        hit = C.c_int()
+        v = r1cs.view() if r1cs is not None else None
+        cid = bytes(circuit_id) if circuit_id is not None else None
+        _check(ctx.handle, ctx._lib.zg16_r1cs_cached(ctx.handle, cid, len(cid) if cid else 0,
+                                                     C.byref(v) if v is not None else None, C.byref(self.handle),
+                                                     C.byref(hit)))
+        if not self.handle:
+            return None, False
+        return self, bool(hit.value)
 
     def density(self):
         a, bi, ba = C.c_size_t(), C.c_size_t(), C.c_size_t()
@@ -302,9 +352,9 @@ class DeviceR1CS:
         return outs
 
     def free(self):
-        if self.handle:
+        if self.handle and not getattr(self, "_borrowed", False):
             self.ctx._lib.zg16_r1cs_free(self.handle)
-            self.handle = C.c_void_p()
+        self.handle = C.c_void_p()
 
     def __del__(self):
         try:
@@ -368,6 +418,19 @@ class ProvingAssignment:
         return zi, za
 
 
+class WitnessAssignment(ProvingAssignment):
+    """Constraint system for a circuit whose matrices are already resident (DeviceR1CS.cached hit): it keeps the
+    witness and drops every row, so synthesis pays for witness generation only.  bellman hands `enforce` three
+    closures; a Rust equivalent never calls them, which is where the per-row cost of
+    zinc-vm/src/constraint_systems/dedup.rs:30-69 and logging.rs:99-111 goes away."""
+
+    def enforce(self, a_lc, b_lc, c_lc):
+        pass
+
+    def finalize_inputs(self):
+        pass
+
+
 def prove_recorded(ctx, dev_key, dev_r1cs, z_in, z_aux, r_mont, s_mont):
     """zg16_prove on uploaded handles; z_in/z_aux/r/s are Montgomery limb arrays."""
     raw = _lib.Proof()
@@ -398,22 +461,27 @@ def prove_from_evals(ctx, dev_key, dev_r1cs, a, b, c, z_in, z_aux, r_mont, s_mon
     return Proof(raw)
 
 
-def create_proof(circuit, params, r, s, ctx=None):
-    """bellman `create_proof(circuit, params, r, s)`; r, s are canonical integers in Fr."""
-    ctx = ctx or Context()
-    pa = ProvingAssignment()
+def create_proof(circuit, params, r, s, ctx=None, circuit_id=None):
+    """bellman `create_proof(circuit, params, r, s)`; r, s are canonical integers in Fr.
+
+    The key and the matrices stay resident in the context's cache (the process-wide default context unless one is
+    given), so the second proof with the same `params` skips the upload and table expansion.  circuit_id (bytes,
+    e.g. a digest of the bytecode and the method) names the circuit: once its matrices are resident, synthesis runs
+    against a WitnessAssignment and records no rows."""
+    ctx = ctx or Context.default()
+    mat = None
+    if circuit_id is not None:
+        mat, _ = DeviceR1CS.cached(ctx, circuit_id)
+    pa = WitnessAssignment() if mat is not None else ProvingAssignment()
     pa.alloc_input(1)
     circuit.synthesize(pa)
     pa.finalize_inputs()
-    key = params.upload(ctx)
-    mat = pa.r1cs().upload(ctx)
+    key, _ = params.cached(ctx)
+    if mat is None:
+        mat, _ = DeviceR1CS.cached(ctx, circuit_id, pa.r1cs())
     zi, za = pa.witness()
     rs = ints_to_mont([r, s], R_MOD)
-    try:
-        return prove_recorded(ctx, key, mat, zi, za, rs[0], rs[1])
-    finally:
-        key.free()
-        mat.free()
+    return prove_recorded(ctx, key, mat, zi, za, rs[0], rs[1])
 
 
 def random_fr(rng=None):
@@ -429,8 +497,8 @@ def random_fr(rng=None):
             return raw * pow(MONT_R, -1, R_MOD) % R_MOD
 
 
-def create_random_proof(circuit, params, rng=None, ctx=None):
+def create_random_proof(circuit, params, rng=None, ctx=None, circuit_id=None):
     """bellman `create_random_proof`: r then s drawn from rng (zinc-vm/src/core/circuit/facade.rs:140-153)."""
     r = random_fr(rng)
     s = random_fr(rng)
-    return create_proof(circuit, params, r, s, ctx)
+    return create_proof(circuit, params, r, s, ctx, circuit_id)

@@ -78,6 +78,11 @@ class Circuit {
 
 class ProvingAssignment final : public ConstraintSystem {
  public:
+  // witness_only: the circuit's matrices are already resident (zg16_r1cs_cached knew its id), so rows are dropped
+  // and synthesis pays for the witness alone.  (bellman passes `enforce` three closures; the Rust equivalent never
+  // calls them, which removes the per-row cost of zinc-vm/src/constraint_systems/dedup.rs:30-69.)
+  explicit ProvingAssignment(bool witness_only = false) : witness_only_(witness_only) {}
+  bool witness_only() const { return witness_only_; }
   std::vector<Limbs> z_in, z_aux;
   std::vector<uint64_t> row_ptr[3] = {{0}, {0}, {0}};
   std::vector<uint32_t> col[3];
@@ -94,6 +99,7 @@ class ProvingAssignment final : public ConstraintSystem {
     return Variable::input((uint32_t)z_in.size() - 1);
   }
   void enforce(const LinearCombination& a, const LinearCombination& b, const LinearCombination& c) override {
+    if (witness_only_) return;
     const LinearCombination* lcs[3] = {&a, &b, &c};
     for (int k = 0; k < 3; k++) {
       for (const auto& t : lcs[k]->terms) {
@@ -105,6 +111,7 @@ class ProvingAssignment final : public ConstraintSystem {
   }
   // the rows bellman appends after synthesis
   void finalize_inputs() {
+    if (witness_only_) return;
     LinearCombination empty;
     for (uint32_t i = 0; i < z_in.size(); i++) enforce(LinearCombination().add(fr_one(), Variable::input(i)), empty, empty);
   }
@@ -121,6 +128,9 @@ class ProvingAssignment final : public ConstraintSystem {
     }
     return v;
   }
+
+ private:
+  bool witness_only_;
 };
 
 // bellman `Parameters<Bn256>`: affine points as Montgomery limbs (x || y; G2: x.c0 x.c1 y.c0 y.c1).
@@ -154,10 +164,43 @@ class Prover {
   ~Prover() {
     zg16_pk_free(pk_);
     zg16_r1cs_free(r1cs_);
-    zg16_ctx_destroy(ctx_);
+    if (owns_ctx_) zg16_ctx_destroy(ctx_);
   }
   Prover(const Prover&) = delete;
   Prover& operator=(const Prover&) = delete;
+
+  // The process-wide prover of a GPU: it works on zg16_default_ctx, whose cache keeps keys and circuits resident
+  // between create_proof calls.  Never destroyed (the context lives until zg16_shutdown).
+  static Prover& shared(int device = 0) {
+    static Prover* provers[64] = {};
+    if (device < 0 || device >= 64) throw SynthesisError(ZG16_ERR_INVALID_ARGUMENT, "bad device index");
+    if (!provers[device]) {
+      zg16_ctx* ctx = nullptr;
+      zg16_status st = zg16_default_ctx(device, &ctx);
+      if (st != ZG16_OK) throw SynthesisError(st, "cannot create a GPU context");
+      provers[device] = new Prover(ctx);
+    }
+    return *provers[device];
+  }
+  // Resident handles from the context's cache (owned by the context, not by this object).
+  bool use_cached_key(const Parameters& p) {
+    release_own();
+    zg16_pk_view v = p.view();
+    int hit = 0;
+    check(zg16_pk_cached(ctx_, &v, 0, &pk_, &hit));
+    return hit != 0;
+  }
+  // circuit_id empty: the matrices are digested.  pa null: look-up only; false when the circuit is unknown.
+  bool use_cached_circuit(const std::string& circuit_id, const ProvingAssignment* pa) {
+    zg16_r1cs_free(r1cs_);
+    r1cs_ = nullptr;
+    zg16_r1cs_view v{};
+    if (pa) v = pa->view();
+    int hit = 0;
+    check(zg16_r1cs_cached(ctx_, circuit_id.empty() ? nullptr : (const uint8_t*)circuit_id.data(), circuit_id.size(),
+                           pa ? &v : nullptr, &r1cs_, &hit));
+    return r1cs_ != nullptr;
+  }
 
   void load_key(const Parameters& p) {
     zg16_pk_free(pk_);
@@ -180,10 +223,16 @@ class Prover {
   zg16_ctx* ctx() { return ctx_; }
 
  private:
+  explicit Prover(zg16_ctx* shared_ctx) : ctx_(shared_ctx), owns_ctx_(false) {}
+  void release_own() {
+    zg16_pk_free(pk_);  // (ignores handles the cache owns)
+    pk_ = nullptr;
+  }
   void check(zg16_status st) {
     if (st != ZG16_OK) throw SynthesisError(st, zg16_last_error(ctx_));
   }
   zg16_ctx* ctx_ = nullptr;
+  bool owns_ctx_ = true;
   zg16_pk* pk_ = nullptr;
   zg16_r1cs* r1cs_ = nullptr;
 };
@@ -197,6 +246,24 @@ inline Proof create_proof(Circuit& circuit, const Parameters& params, const Limb
   pa.finalize_inputs();
   prover.load_key(params);
   prover.load_circuit(pa);
+  return prover.prove(pa, r, s);
+}
+
+// The same against the process-wide prover: key and matrices stay resident between calls, so a loop like
+// zinc-tester's (zinc-tester/src/runners/proof_check.rs:122) uploads each key once.  circuit_id (any bytes naming
+// the circuit, e.g. a digest of bytecode + method; empty = digest the matrices) lets later proofs of a known
+// circuit synthesize the witness only.
+inline Proof create_proof(Circuit& circuit, const Parameters& params, const Limbs& r, const Limbs& s,
+                          const std::string& circuit_id = std::string(), int device = 0) {
+  Prover& prover = Prover::shared(device);
+  const bool known = !circuit_id.empty() && prover.use_cached_circuit(circuit_id, nullptr);
+  ProvingAssignment pa(known);
+  Limbs one = fr_one();
+  pa.alloc_input(&one);
+  circuit.synthesize(pa);
+  pa.finalize_inputs();
+  prover.use_cached_key(params);
+  if (!known) prover.use_cached_circuit(circuit_id, &pa);
   return prover.prove(pa, r, s);
 }
 

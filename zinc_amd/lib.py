@@ -54,6 +54,12 @@ class Partial(C.Structure):
                 ("b2", C.c_uint64 * 32)]
 
 
+class CacheCounts(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in
+                ("keys", "circuits", "key_hits", "key_misses", "circuit_hits", "circuit_misses", "evictions",
+                 "key_bytes")]
+
+
 class Timings(C.Structure):
     _fields_ = [(n, C.c_float) for n in
                 ("upload_ms", "spmv_ms", "ntt_ms", "msm_g1_ms", "msm_g2_ms", "finish_ms", "total_ms")]
@@ -70,6 +76,14 @@ SYMBOLS = [
     ("zg16_pk_upload_bytes", C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
                                        C.POINTER(C.c_void_p)]),
     ("zg16_pk_vk_view", C.c_int, [C.c_void_p, C.POINTER(PkView)]),
+    ("zg16_default_ctx", C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    ("zg16_shutdown", None, []),
+    ("zg16_pk_cached", C.c_int, [C.c_void_p, C.POINTER(PkView), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
+    ("zg16_pk_cache_holds", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("zg16_r1cs_cached", C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(R1csView), C.POINTER(C.c_void_p),
+                                   C.POINTER(C.c_int)]),
+    ("zg16_cache_clear", C.c_int, [C.c_void_p]),
+    ("zg16_cache_stats", C.c_int, [C.c_void_p, C.POINTER(CacheCounts)]),
     ("zg16_r1cs_upload", C.c_int, [C.c_void_p, C.POINTER(R1csView), C.POINTER(C.c_void_p)]),
     ("zg16_r1cs_free", None, [C.c_void_p]),
     ("zg16_r1cs_density", C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
