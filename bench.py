@@ -52,8 +52,10 @@ def parse():
                     help="skip the secondary measurements (2^24 prove, dense 2^20, stand-alone 2^26 multiexp / transform, cold start)")
     ap.add_argument("--secondary-log-rows", type=int, default=24, help="circuit size of the secondary large prove")
     ap.add_argument("--secondary-log-n", type=int, default=26, help="size of the stand-alone multiexp / transform")
-    ap.add_argument("--split-transforms", choices=("auto", "on", "off"), default="auto",
-                    help="run the A/B/C transform chains on different ranks (auto: 3+ ranks and 2^22+ rows)")
+    ap.add_argument("--split-transforms", choices=("auto", "on", "off", "sharded"), default="auto",
+                    help="how N > 1 ranks share the transforms: off = every rank repeats them, on = the A/B/C chains on "
+                         "three ranks, sharded = every transform over all ranks (2, 4 or 8), a, b, c sharded through H; "
+                         "auto: sharded from 2^21 rows on 2/4/8 ranks, chains from 2^22 rows on 3+ ranks, else off")
     return ap.parse_args()
 
 
@@ -145,8 +147,14 @@ class ProveCase:
         self.r1cs = self.circ.r1cs()
         self.generate_s = time.time() - t0
         t0 = time.time()
-        self.key = self.params.upload(ctx, d.rank, d.world)
         self.mat = self.r1cs.upload(ctx)
+        self.sharded = None
+        if split == "sharded":
+            from zinc_amd.distributed import ShardedProver
+            self.sharded = ShardedProver(ctx, self.params, self.mat, d.rank, d.world, d.dev)
+            self.key = None
+        else:
+            self.key = self.params.upload(ctx, d.rank, d.world)
         self.zi, self.za = self.circ.witness()
         self.z_in_dev = torch.from_numpy(self.zi.view(np.int64)).cuda()
         self.z_aux_dev = torch.from_numpy(self.za.view(np.int64)).cuda()
@@ -159,12 +167,17 @@ class ProveCase:
     def step(self):
         from zinc_amd.distributed import prove_sharded
         d = self.d
+        if self.sharded:
+            return self.sharded.prove(self.z_in_dev.data_ptr(), self.z_aux_dev.data_ptr(), 1, self.rs[0], self.rs[1])
         return prove_sharded(self.ctx, self.key, self.mat, self.z_in_dev.data_ptr(), self.z_aux_dev.data_ptr(), 1,
                              self.pk_view, self.rs[0], self.rs[1], d.rank, d.world, d.dev if d.world > 1 else None,
-                             split_transforms=self.split)
+                             split_transforms=bool(self.split))
 
     def free(self):
-        self.key.free()
+        if self.sharded:
+            self.sharded.free()
+        if self.key:
+            self.key.free()
         self.mat.free()
         del self.z_in_dev, self.z_aux_dev
 
@@ -214,7 +227,7 @@ def secondary_block(ctx, d, args, split_for):
                     "ms_per_proof": 1e3 * sec, "constraints_per_s": n_rows / sec, "proofs_timed": reps,
                     "stage_ms_last_proof": stage, "roofline": accumulate_roofline(stats),
                     "generate_s_untimed": case.generate_s, "key_upload_and_tables_s": case.upload_s,
-                    "split_transforms": bool(case.split)}
+                    "split_transforms": case.split or False}
         finally:
             case.free()
 
@@ -367,8 +380,17 @@ def main():
     n_rows = 1 << args.log_rows
 
     def split_for(log_rows):
-        on = args.split_transforms == "on" or (args.split_transforms == "auto" and world >= 3 and log_rows >= 22)
-        return on and world > 1
+        """False (every rank repeats the transforms), True (A/B/C chains on three ranks) or "sharded"."""
+        if world == 1 or args.split_transforms == "off":
+            return False
+        can_shard = world in (2, 4, 8) and log_rows >= 2 * (world.bit_length() - 1) + 1
+        if args.split_transforms == "sharded":
+            return "sharded" if can_shard else False
+        if args.split_transforms == "on":
+            return True
+        if can_shard and log_rows >= 21:
+            return "sharded"
+        return world >= 3 and log_rows >= 22
 
     t0 = time.time()
     case = ProveCase(ctx, d, args.log_rows, args.dense, split_for(args.log_rows))
@@ -505,7 +527,7 @@ def main():
             "config": {"workload": "synthetic zinc-shaped R1CS, 2^%d rows (%s witness), full Groth16 prove incl. G2 multiexp"
                                    % (args.log_rows, "dense" if args.dense else "80% bit"),
                        "n_inputs": circ.n_inputs, "n_aux": circ.n_aux, "nnz": [int(m[1].shape[0]) for m in r1cs.mats],
-                       "a_aux_density": dens[0], "b_aux_density": dens[2], "parallelism": "msm-point-range x%d%s" % (world, ", A/B/C transform chains on 3 ranks" if split else "")},
+                       "a_aux_density": dens[0], "b_aux_density": dens[2], "parallelism": "msm-point-range x%d%s" % (world, ", transforms sharded over all ranks" if split == "sharded" else ", A/B/C transform chains on 3 ranks" if split else "")},
             "constraints_per_s": n_rows / (ms_per_step / 1e3),
             "stage_ms_last_step": stage,
             "kernels": per_kernel,

@@ -235,6 +235,48 @@ zg16_status zg16_prove_partial_h(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1
                                  const uint64_t* h_dev, zg16_partial* out);
 unsigned    zg16_r1cs_log_domain(const zg16_r1cs* r1cs);
 
+/* ---- one proof over several GPUs, transforms sharded too ---------------------------------------
+ * No counterpart upstream (bellman_ce proves on one host); the proof is the same group elements however it is split.
+ * With G = 2, 4 or 8 GPUs and m = G L rows (m >= 2 G^2), GPU s evaluates the rows of its blocks, holds coefficient
+ * s + G j of every polynomial at slot j, and owns the h points of those indices (zg16_pk_upload_cyclic_h: h cyclic,
+ * l / a / b_g1 / b_g2 by contiguous range as zg16_pk_upload shards them).  What crosses GPUs: three all-to-all rounds
+ * of 3, 2 and 1 vectors of 32 L bytes, and one zg16_partial per GPU.
+ *
+ * Per GPU: zg16_hshard_create once per (key, circuit); then per proof, for stage = 0, 1, 2, 3:
+ *     zg16_hshard_stage(hs, stage, z_in, z_aux, witness_on_device, work, got, &n)   (witness used by stage 0 only)
+ *     if n > 0: exchange -- for each of the first n vectors (zg16_hshard_vector_bytes each, back to back) of `work`,
+ *               chunk h (1/G of the vector) goes to GPU h, which stores the chunk it gets from GPU g at chunk g of the
+ *               same vector of its `got` (an equal-split all-to-all per vector).  The call returns with `work` ready.
+ * and zg16_hshard_finish for this GPU's partial sums; zg16_prove_finish adds the partials of all GPUs.
+ * work, got: device memory of the caller, 3 vectors each.  zg16_hshard_stage(.., 0, ..) restarts a proof at any time. */
+typedef struct zg16_hshard zg16_hshard;
+zg16_status zg16_pk_upload_cyclic_h(zg16_ctx* ctx, const zg16_pk_view* view, int shard_index, int shard_count,
+                                    zg16_pk** out);
+zg16_status zg16_hshard_create(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1cs* r1cs, unsigned log_shards,
+                               unsigned shard, zg16_hshard** out);
+void        zg16_hshard_free(zg16_hshard* hs);
+size_t      zg16_hshard_vector_bytes(const zg16_hshard* hs);
+zg16_status zg16_hshard_stage(zg16_hshard* hs, int stage, const uint64_t* z_in, const uint64_t* z_aux,
+                              int witness_on_device, uint64_t* work_dev, uint64_t* got_dev, int* n_exchange);
+zg16_status zg16_hshard_finish(zg16_hshard* hs, zg16_partial* out);
+
+/* The same driven from ONE process that sees all the GPUs (what a Rust host linking this library can do without a
+ * launcher): a context per listed device, a host thread per GPU during a call, peer-to-peer copies for the
+ * exchanges.  zg16_multi_load shards the key and uploads the matrices to every GPU (previous ones are released);
+ * sharded_transforms: 1 = the schedule above (needs 2, 4 or 8 devices), 0 = every GPU repeats the row evaluation
+ * and the transforms and only the multiexps are split (any device count), -1 = choose (sharded from 2^21 rows).
+ * zg16_multi_prove: witness and (r, s) in host memory, as zg16_prove.  A device id may be listed more than once
+ * (several contexts on one GPU), which is how a one-GPU machine rehearses the schedule. */
+typedef struct zg16_multi zg16_multi;
+zg16_status zg16_multi_create(const int* device_ids, int n_devices, zg16_multi** out);
+void        zg16_multi_destroy(zg16_multi* mg);
+const char* zg16_multi_last_error(const zg16_multi* mg);
+zg16_status zg16_multi_load(zg16_multi* mg, const zg16_pk_view* key, const zg16_r1cs_view* circuit,
+                            int sharded_transforms);
+int         zg16_multi_sharded_transforms(const zg16_multi* mg);
+zg16_status zg16_multi_prove(zg16_multi* mg, const uint64_t* z_in, const uint64_t* z_aux, const uint64_t r[4],
+                             const uint64_t s[4], zg16_proof* out);
+
 /* ---- stand-alone stages (each is one stage of bellman's prover) ------------------------------
  * data: 2^log_n Montgomery Fr, natural order in and out, transformed in place.
  * inverse = 0: `EvaluationDomain::fft`; inverse = 1: `ifft` (includes the 1/m factor);

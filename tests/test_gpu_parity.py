@@ -751,3 +751,97 @@ def test_sharded_prove_with_split_transforms(world):
             raise
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert "bit-identical" in outs[0], outs[0]
+
+
+@pytest.mark.gpu
+def test_spmv_coefficient_codes(gpu_ctx):
+    """Row evaluation with every kind of coefficient code: one, minus one, +-2^k for every k, a few thousand other
+    values, and more distinct values than there are codes (those terms fall back to the full coefficient array)."""
+    rng = np.random.default_rng(5)
+    pa = ProvingAssignment()
+    pa.alloc_input(1)
+    zs = [int.from_bytes(rng.bytes(32), "little") % R_MOD for _ in range(64)]
+    vs = [pa.alloc(v) for v in zs]
+    coeffs = [1, R_MOD - 1] + [1 << k for k in range(1, 254)] + [R_MOD - (1 << k) for k in range(1, 254)]
+    coeffs += [3, 5, R_MOD - 3, (1 << 200) + 1]
+    coeffs += [int.from_bytes(rng.bytes(32), "little") % R_MOD or 1 for _ in range(70000)]
+    want = []
+    for i, c in enumerate(coeffs):
+        v, w = i % 64, (7 * i + 1) % 64
+        if v == w:
+            w = (w + 1) % 64
+        pa.enforce([(vs[v], c)], [(0, 1), (vs[w], c)], [(vs[w], 1), (vs[v], R_MOD - 1)])
+        want.append((c * zs[v] % R_MOD, (1 + c * zs[w]) % R_MOD, (zs[w] - zs[v]) % R_MOD))
+    # one long row (a wavefront's worth of terms) mixing the kinds
+    long_lc = [(vs[i % 64] if i < 64 else (i - 63), coeffs[(5 * i) % 600]) for i in range(64)]
+    pa.enforce(long_lc, [], [])
+    want.append((sum(c * (zs[i]) for i, (_, c) in enumerate(long_lc)) % R_MOD, 0, 0))
+    pa.finalize_inputs()
+    mat = pa.r1cs().upload(gpu_ctx)
+    zi, za = pa.witness()
+    a, b, c = (mont_to_ints(x, R_MOD) for x in mat.spmv(zi, za))
+    n = len(want)
+    assert a[:n] == [w[0] for w in want]
+    assert b[:n] == [w[1] for w in want]
+    assert c[:n] == [w[2] for w in want]
+    mat.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_transforms_over_ranks_prove(world):
+    """`world` processes on one GPU (gloo stands in for RCCL): a, b, c stay sharded through the whole H computation
+    (zg16_hshard_*), h query cyclic -- bit-identical to zg16_prove."""
+    outs = _run_ranks("gpu_hshard_worker.py", world, 29560 + world, 12)
+    assert "bit-identical" in outs[0], outs[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices,sharded,log_rows", [([0, 0], True, 12), ([0, 0, 0, 0], True, 12), ([0, 0], True, 16),
+                                                       ([0, 0, 0, 0], True, 16), ([0] * 8, True, 13), ([0, 0, 0], False, 12)])
+def test_multi_gpu_prover_in_one_process(gpu_ctx, devices, sharded, log_rows):
+    """zg16_multi_*: one process, a context per listed device (all on GPU 0 here), peer copies for the exchanges.
+    Sharded transforms at 2, 4 and 8 shards and the replicated schedule at 3: the proof equals zg16_prove's."""
+    from zinc_amd import workload
+    from zinc_amd.groth16 import MultiProver
+    circ = workload.SyntheticCircuit(1 << log_rows, n_pub=4, seed=(log_rows, 9, 9, 9))
+    params = workload.generate_parameters(gpu_ctx, circ, dict(k1=3, k2=5, alpha=7, beta=11, gamma=13, delta=17, tau=31))
+    r1cs = circ.r1cs()
+    zi, za = circ.witness()
+    rs = ints_to_mont([0xABCDEF, 0x13579B], R_MOD)
+    key, mat = params.upload(gpu_ctx), r1cs.upload(gpu_ctx)
+    want = prove_recorded(gpu_ctx, key, mat, zi, za, rs[0], rs[1])
+    key.free()
+    mat.free()
+    mp = MultiProver(devices)
+    assert mp.load(params, r1cs, sharded_transforms=sharded) == sharded
+    for _ in range(2):
+        got = mp.prove(zi, za, rs[0], rs[1])
+        assert got.as_tuple() == want.as_tuple()
+    mp.close()
+
+
+@pytest.mark.gpu
+def test_multi_gpu_prover_errors(gpu_ctx):
+    from zinc_amd.groth16 import MultiProver
+    fx = golden("prove_tiny_1.json")
+    circ, key = FixtureCircuit(fx), FixtureKey(fx)
+    pa = ProvingAssignment()
+    pa.alloc_input(1)
+    circ.synthesize(pa)
+    pa.finalize_inputs()
+    mp = MultiProver([0, 0, 0])
+    with pytest.raises(SynthesisError) as e:      # three GPUs cannot shard the transforms
+        mp.load(Parameters.from_points(key), pa.r1cs(), sharded_transforms=True)
+    assert e.value.status_name == "InvalidArgument"
+    assert mp.load(Parameters.from_points(key), pa.r1cs()) is False
+    zi, za = pa.witness()
+    rs = ints_to_mont([int(fx["r"], 16), int(fx["s"], 16)], R_MOD)
+    assert mp.prove(zi, za, rs[0], rs[1]).as_tuple() == fixture_proof(fx)
+    bad = Parameters.from_points(key)
+    bad.delta_g2 = np.zeros((1, 16), dtype=np.uint64)
+    mp.load(bad, pa.r1cs())
+    with pytest.raises(SynthesisError) as e:
+        mp.prove(zi, za, rs[0], rs[1])
+    assert e.value.status_name == "UnexpectedIdentity"
+    mp.close()

@@ -94,8 +94,10 @@ Fr load_fr(const uint64_t* p) {
   return r;
 }
 
+}  // namespace
+
 // Device witness z = z_in || z_aux in scratch slot 3.
-zg16_status stage_witness(zg16_ctx* ctx, const zg16_r1cs* r, const uint64_t* z_in, const uint64_t* z_aux,
+zg16_status zg::stage_witness(zg16_ctx* ctx, const zg16_r1cs* r, const uint64_t* z_in, const uint64_t* z_aux,
                           int on_device, Fr** z_out) {
   if (!z_in || (r->n_aux && !z_aux)) return fail(ctx, ZG16_ERR_ASSIGNMENT_MISSING, "witness pointer is NULL");
   Fr* z;
@@ -107,7 +109,7 @@ zg16_status stage_witness(zg16_ctx* ctx, const zg16_r1cs* r, const uint64_t* z_i
   return ZG16_OK;
 }
 
-zg16_status check_key_fits(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1cs* r) {
+zg16_status zg::check_key_fits(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1cs* r) {
   const size_t m = (size_t)1 << r->log_m;
   if (pk->n_h + 1 < m || pk->n_l != r->n_aux || pk->n_a != r->n_a || pk->n_b1 != r->n_b || pk->n_b2 != r->n_b)
     return fail(ctx, ZG16_ERR_MALFORMED_KEY,
@@ -115,6 +117,8 @@ zg16_status check_key_fits(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1cs* r)
                 pk->n_h, m - 1, pk->n_l, r->n_aux, pk->n_a, r->n_a, pk->n_b1, pk->n_b2, r->n_b);
   return ZG16_OK;
 }
+
+namespace {
 
 template <class F, class RunFn>
 zg16_status msm_entry(zg16_ctx* ctx, const uint64_t* bases, size_t n_bases, const uint64_t* scalars,
@@ -198,6 +202,7 @@ void zg16_ctx_destroy(zg16_ctx* ctx) {
   drop_graphs(ctx, nullptr);
   ntt_free_domains(ctx);
   ntt_free_cross_tables(ctx);
+  ntt_free_hshard_tables(ctx);
   for (auto& s : ctx->scratch)
     if (s) (void)hipFree(s);
   for (auto& e : ctx->ev)
@@ -220,6 +225,16 @@ zg16_status zg16_ctx_set_stream(zg16_ctx* ctx, void* hip_stream) {
 
 // ---------------------------------------------------------------------------------- proving key
 zg16_status zg16_pk_upload(zg16_ctx* ctx, const zg16_pk_view* v, int shard_index, int shard_count, zg16_pk** out) {
+  return zg::pk_upload_impl(ctx, v, shard_index, shard_count, false, out);
+}
+
+zg16_status zg16_pk_upload_cyclic_h(zg16_ctx* ctx, const zg16_pk_view* v, int shard_index, int shard_count, zg16_pk** out) {
+  return zg::pk_upload_impl(ctx, v, shard_index, shard_count, true, out);
+}
+}  // extern "C"
+
+zg16_status zg::pk_upload_impl(zg16_ctx* ctx, const zg16_pk_view* v, int shard_index, int shard_count, bool h_cyclic,
+                               zg16_pk** out) {
   if (!ctx || !v || !out || shard_count < 1 || shard_index < 0 || shard_index >= shard_count)
     return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "bad arguments to zg16_pk_upload");
   *out = nullptr;
@@ -235,6 +250,18 @@ zg16_status zg16_pk_upload(zg16_ctx* ctx, const zg16_pk_view* v, int shard_index
   pk->shard_count = shard_count;
   pk->n_h = v->n_h; pk->n_l = v->n_l; pk->n_a = v->n_a; pk->n_b1 = v->n_b_g1; pk->n_b2 = v->n_b_g2;
   shard_range(v->n_h, shard_index, shard_count, &pk->lo_h, &pk->hi_h);
+  // h_cyclic: this shard holds h[shard_index + shard_count * j] at slot j instead of a contiguous range -- the layout
+  // the H coefficients come out in when the transforms are spread over the GPUs (shard.hip)
+  std::vector<uint64_t> h_gathered;
+  if (h_cyclic) {
+    const size_t s = (size_t)shard_index, G = (size_t)shard_count;
+    const size_t n_local = v->n_h > s ? (v->n_h - s + G - 1) / G : 0;
+    h_gathered.resize(8 * n_local);
+    for (size_t j = 0; j < n_local; j++) memcpy(&h_gathered[8 * j], v->h + 8 * (s + G * j), 64);
+    pk->h_cyclic = true;
+    pk->lo_h = 0;
+    pk->hi_h = n_local;
+  }
   shard_range(v->n_l, shard_index, shard_count, &pk->lo_l, &pk->hi_l);
   shard_range(v->n_a, shard_index, shard_count, &pk->lo_a, &pk->hi_a);
   shard_range(v->n_b_g1, shard_index, shard_count, &pk->lo_b, &pk->hi_b);
@@ -244,7 +271,8 @@ zg16_status zg16_pk_upload(zg16_ctx* ctx, const zg16_pk_view* v, int shard_index
   pk->table_c = msm_table_window(largest, 1);
   pk->table_c_h = msm_table_window(pk->hi_h - pk->lo_h, 0);
   pk->table_c_g2 = msm_table_window(pk->hi_b - pk->lo_b, 2);
-  ZG_TRY(upload_query<Fq>(ctx, &pk->h, v->h + 8 * pk->lo_h, pk->hi_h - pk->lo_h, pk->table_c_h, &pk->h_d, &pk->device_bytes));
+  ZG_TRY(upload_query<Fq>(ctx, &pk->h, h_cyclic ? h_gathered.data() : v->h + 8 * pk->lo_h, pk->hi_h - pk->lo_h, pk->table_c_h,
+                          &pk->h_d, &pk->device_bytes));
   ZG_TRY(upload_query<Fq>(ctx, &pk->l, v->l + 8 * pk->lo_l, pk->hi_l - pk->lo_l, pk->table_c, &pk->l_d, &pk->device_bytes));
   ZG_TRY(upload_query<Fq>(ctx, &pk->a, v->a + 8 * pk->lo_a, pk->hi_a - pk->lo_a, pk->table_c, &pk->a_d, &pk->device_bytes));
   ZG_TRY(upload_query<Fq>(ctx, &pk->b1, v->b_g1 + 8 * pk->lo_b, pk->hi_b - pk->lo_b, pk->table_c, &pk->b1_d, &pk->device_bytes));
@@ -258,6 +286,8 @@ zg16_status zg16_pk_upload(zg16_ctx* ctx, const zg16_pk_view* v, int shard_index
   *out = pk.release();
   return ZG16_OK;
 }
+
+extern "C" {
 
 void zg16_pk_free(zg16_pk* pk) {
   if (!pk || pk->cached) return;  // a cached key belongs to its context (zg16_cache_clear / zg16_ctx_destroy)
@@ -326,7 +356,16 @@ zg16_status zg16_r1cs_upload(zg16_ctx* ctx, const zg16_r1cs_view* v, zg16_r1cs**
     d.n_long = (uint32_t)longs.size();
     ZG_TRY(dev_alloc_copy(ctx, &d.row_ptr, rp.data(), rp.size()));
     ZG_TRY(dev_alloc_copy(ctx, &d.col, flat.data(), nnz));
-    ZG_TRY(dev_alloc_copy(ctx, &d.coeff, m.coeff, nnz));
+    {
+      std::vector<uint16_t> codes;
+      std::vector<Fr> table;
+      bool needs_full = false;
+      spmv_encode_coeffs(m.coeff, nnz, codes, table, &needs_full);
+      d.n_table = (uint32_t)table.size();
+      ZG_TRY(dev_alloc_copy(ctx, &d.code, codes.data(), nnz));
+      ZG_TRY(dev_alloc_copy(ctx, &d.table, table.data(), table.size()));
+      if (needs_full) ZG_TRY(dev_alloc_copy(ctx, &d.coeff, m.coeff, nnz));
+    }
     ZG_TRY(dev_alloc_copy(ctx, &d.long_rows, longs.data(), longs.size()));
   }
   // query maps: A treats every input as dense (upstream tracks A density for aux only)
@@ -361,6 +400,7 @@ void zg::r1cs_destroy(zg16_r1cs* r) {
   }
   for (auto& m : r->m) {
     (void)hipFree(m.row_ptr); (void)hipFree(m.col); (void)hipFree(m.coeff); (void)hipFree(m.long_rows);
+    (void)hipFree(m.code); (void)hipFree(m.table);
   }
   (void)hipFree(r->a_map); (void)hipFree(r->b_map);
   delete r;
@@ -437,6 +477,7 @@ static zg16_status prove_partial_impl(zg16_ctx* ctx, const zg16_pk* pk, const zg
                                       Assembly* early = nullptr, const RowEvals* evals = nullptr) {
   if (!ctx || !pk || !r || !out) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "bad arguments to zg16_prove_partial");
   if (pk->ctx != ctx || r->ctx != ctx) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "handles belong to another context");
+  if (pk->h_cyclic) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "a key uploaded with zg16_pk_upload_cyclic_h proves through zg16_hshard_*");
   ZG_TRY(check_key_fits(ctx, pk, r));
   ZG_HIP(ctx, hipSetDevice(ctx->device));
   zg16_timings& tm = ctx->timings;

@@ -54,6 +54,7 @@ struct zg16_ctx {
   std::string last_error = "";
   std::map<unsigned, zg::NttDomain*> domains;  // per log2 size
   std::map<uint64_t, void*> cross_tables;      // twiddles of the cross-GPU step of a sharded transform
+  std::map<uint64_t, void*> hshard_tables;     // strided factor tables of an H computation spread over GPUs
   // Proofs replayed as HIP graphs, per (key, matrices) pair.  Every device buffer a proof touches belongs to the
   // context, the key or the matrices, so a captured proof stays valid until one of the scratch arenas moves
   // (scratch_gen) or a handle is freed.
@@ -254,6 +255,12 @@ void cache_free(zg16_ctx* ctx);  // cache.hip: releases every cached handle (the
 void default_ctx_forget(zg16_ctx* ctx);  // cache.hip: zg16_default_ctx stops handing this context out
 void ntt_free_domains(zg16_ctx* ctx);
 void ntt_free_cross_tables(zg16_ctx* ctx);
+void ntt_free_hshard_tables(zg16_ctx* ctx);
+struct HShardTables;
+zg16_status hshard_tables(zg16_ctx* ctx, unsigned log_m, unsigned log_g, unsigned shard, const HShardTables** out);
+zg16_status hshard_local_ntt(zg16_ctx* ctx, unsigned log_l, const HShardTables* t, const Fr* src, Fr* dst, bool inverse,
+                             int which, const Fr* subvec);
+zg16_status mul_vec_device(zg16_ctx* ctx, Fr* a, const Fr* b, size_t n);
 // The cross-GPU step of a 2^log_n-point transform sharded over 2^log_g GPUs (see ntt.hip), in place on
 // this shard's 2^(log_n - log_g) elements.
 zg16_status ntt_cross_device(zg16_ctx* ctx, Fr* data, unsigned log_n, unsigned log_g, unsigned shard, bool inverse);

@@ -541,6 +541,99 @@ zg16_status h_pipeline_device(zg16_ctx* ctx, Fr* a, Fr* b, Fr* c, unsigned log_m
   return ntt_raw(ctx, d, b, a, true, nullptr, &finish);
 }
 
+// ---- pieces of an H computation whose transforms are spread over G GPUs (shard.hip drives them) -------
+// GPU s of G holds element s + G j of every coefficient vector at slot j (j < L = m / G).  Factors that the
+// single-GPU pipeline takes from its natural-order tables are needed at those strided indices here, so each
+// (domain, shard count, shard) gets its own tables of L entries:
+//   gm[j] = g^(s + G j) / L            (1/L of the local inverse transform and the coset factor in one)
+//   hz[j] = g^-(s + G j) / (L Z)       (trailing factor of the final inverse transform, Z = g^m - 1)
+//   kz    = 1 / (L Z)                  (a single constant)
+// The 1/G of every inverse transform is part of ntt_cross_device's twiddles.
+struct HShardTables {
+  Fr29 *gm = nullptr, *hz = nullptr, *kz = nullptr;
+  void* block = nullptr;
+};
+
+zg16_status hshard_tables(zg16_ctx* ctx, unsigned log_m, unsigned log_g, unsigned shard, const HShardTables** out) {
+  const uint64_t key = ((uint64_t)log_m << 32) | (log_g << 16) | shard;
+  auto it = ctx->hshard_tables.find(key);
+  if (it != ctx->hshard_tables.end()) {
+    *out = (const HShardTables*)it->second;
+    return ZG16_OK;
+  }
+  const unsigned log_l = log_m - log_g;
+  const size_t L = (size_t)1 << log_l;
+  HShardTables* t = new HShardTables();
+  void* stage = nullptr;
+  hipError_t e = hipMalloc(&t->block, (2 * L + 8) * sizeof(Fr29));
+  if (e == hipSuccess) e = hipMalloc(&stage, L * sizeof(Fr));
+  if (e != hipSuccess) {
+    (void)hipFree(t->block);
+    delete t;
+    return fail(ctx, ZG16_ERR_OUT_OF_MEMORY, "hipMalloc of the sharded-transform tables failed: %s", hipGetErrorString(e));
+  }
+  t->gm = (Fr29*)t->block;
+  t->hz = t->gm + L;
+  t->kz = t->hz + L;
+  Fr* tmp = (Fr*)stage;
+  const Fr g = from_u64<FrParams>(7), g_inv = inv(g), one = Fr::one();
+  const Fr linv = inv(from_u64<FrParams>((uint64_t)1 << log_l));
+  const Fr zinv = inv(sub(pow_u64(g, (uint64_t)1 << log_m), one));
+  const uint64_t G = (uint64_t)1 << log_g;
+  hipStream_t st = ctx->stream;
+  auto table29 = [&](Fr29* dst, size_t count, const Fr& base, const Fr& c) {
+    k_pow_table<<<(unsigned)((count + 4095) / 4096), 256, 0, st>>>(tmp, (uint32_t)count, base, c);
+    k_to_fr29<<<(unsigned)((count + 255) / 256), 256, 0, st>>>(tmp, dst, (uint32_t)count);
+  };
+  table29(t->gm, L, pow_u64(g, G), mul(pow_u64(g, shard), linv));
+  table29(t->hz, L, pow_u64(g_inv, G), mul(pow_u64(g_inv, shard), mul(linv, zinv)));
+  table29(t->kz, 1, one, mul(linv, zinv));
+  const hipError_t le = hipGetLastError(), se = hipStreamSynchronize(st);
+  (void)hipFree(stage);
+  if (le != hipSuccess || se != hipSuccess) {
+    (void)hipFree(t->block);
+    delete t;
+    return fail(ctx, ZG16_ERR_DEVICE, "building the sharded-transform tables failed: %s", hipGetErrorString(le != hipSuccess ? le : se));
+  }
+  ctx->hshard_tables[key] = t;
+  *out = t;
+  return ZG16_OK;
+}
+
+void ntt_free_hshard_tables(zg16_ctx* ctx) {
+  for (auto& kv : ctx->hshard_tables) {
+    HShardTables* t = (HShardTables*)kv.second;
+    (void)hipFree(t->block);
+    delete t;
+  }
+  ctx->hshard_tables.clear();
+}
+
+// One local L-point transform of the sharded pipeline, unnormalised, with what rides on its last store:
+// which = 0: nothing; 1: times gm[j]; 2: times the constant kz; 3: times hz[j], minus subvec[j].
+zg16_status hshard_local_ntt(zg16_ctx* ctx, unsigned log_l, const HShardTables* t, const Fr* src, Fr* dst, bool inverse,
+                             int which, const Fr* subvec) {
+  NttDomain* d;
+  ZG_TRY(get_domain(ctx, log_l, &d));
+  if (log_l == 0) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "a sharded transform needs at least two elements per GPU");
+  PassExtras ex = {nullptr, nullptr, nullptr, 0};
+  if (which == 1) ex.factor = t->gm;
+  if (which == 2) { ex.factor = t->kz; ex.factor_const = 1; }
+  if (which == 3) { ex.factor = t->hz; ex.subvec = subvec; }
+  return ntt_raw(ctx, d, src, dst, inverse, nullptr, &ex);
+}
+
+__global__ __launch_bounds__(256) void k_mul_vec(Fr* a, const Fr* __restrict__ b, uint32_t n) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) a[i] = mul(a[i], b[i]);
+}
+
+// a[i] *= b[i]
+zg16_status mul_vec_device(zg16_ctx* ctx, Fr* a, const Fr* b, size_t n) {
+  k_mul_vec<<<ew_grid(n), 256, 0, ctx->stream>>>(a, b, (uint32_t)n);
+  ZG_HIP(ctx, hipGetLastError());
+  return ZG16_OK;
+}
+
 // ---- one transform over several GPUs ----------------------------------------------------------
 // N = G * L points over G GPUs (G a power of two, at most 8), one exchange.  GPU g starts with the
 // decimated sequence x[g + G j], j < L.  With k = k2 + L k1:

@@ -9,10 +9,17 @@ namespace zg {
 
 static constexpr uint32_t SPMV_LONG_ROW = 32;  // rows with more terms get a whole wavefront
 
+// Coefficient codes (spmv.hip): 0 = one, 1 = minus one, 2 + k / 256 + k = +-2^(k+1), SPMV_CODE_DICT + i = the i-th
+// other value of the matrix; SPMV_CODE_FULL = read the term's coefficient from the full array.
+static constexpr uint32_t SPMV_CODE_DICT = 512, SPMV_CODE_FULL = 0xffff;
+
 struct R1csMatrix {
   uint32_t* row_ptr = nullptr;  // n_rows + 1
   uint32_t* col = nullptr;      // index into the flat witness z = z_in || z_aux
-  Fr* coeff = nullptr;
+  uint16_t* code = nullptr;     // coefficient code per term
+  Fr* table = nullptr;          // what the codes index (n_table entries)
+  uint32_t n_table = 0;
+  Fr* coeff = nullptr;          // full coefficients; only kept when the matrix has more distinct values than codes
   uint32_t* long_rows = nullptr;
   uint32_t n_long = 0;
   size_t nnz = 0;
@@ -21,6 +28,11 @@ struct R1csMatrix {
 zg16_status spmv_device(zg16_ctx* ctx, const zg16_r1cs* r, const Fr* z, Fr* a, Fr* b, Fr* c);
 // rows of matrix k (0 = A, 1 = B, 2 = C) only
 zg16_status spmv_one_device(zg16_ctx* ctx, const zg16_r1cs* r, int k, const Fr* z, Fr* out);
+// rows (j >> log_blk) * stride + base + (j mod 2^log_blk) for j < n_out (padding rows give zero)
+zg16_status spmv_blocks_device(zg16_ctx* ctx, const zg16_r1cs* r, const Fr* z, Fr* a, Fr* b, Fr* c, uint32_t log_blk,
+                               uint32_t stride, uint32_t base, uint32_t n_out);
+void spmv_encode_coeffs(const uint64_t* coeff, size_t nnz, std::vector<uint16_t>& codes, std::vector<Fr>& table,
+                        bool* needs_full);
 
 }  // namespace zg
 
@@ -43,6 +55,7 @@ struct zg16_pk {
   bool cached = false;  // owned by the context's cache: zg16_pk_free leaves it alone
   size_t device_bytes = 0;  // HBM held by the query tables
   int shard_index = 0, shard_count = 1;
+  bool h_cyclic = false;  // the h query holds h[shard_index + shard_count * j] at slot j ([lo_h, hi_h) = [0, slots))
   // totals of the full key and the [lo, hi) range this shard holds, per query
   size_t n_h = 0, n_l = 0, n_a = 0, n_b1 = 0, n_b2 = 0;
   size_t lo_h = 0, hi_h = 0, lo_l = 0, hi_l = 0, lo_a = 0, hi_a = 0, lo_b = 0, hi_b = 0;
@@ -73,7 +86,13 @@ struct zg16_pk {
 
 namespace zg {
 // Release a handle whoever owns it (zg16_pk_free / zg16_r1cs_free skip handles the cache owns).
+// Device witness z = z_in || z_aux (scratch slot 3 of the context), copied on the context's stream.
+zg16_status stage_witness(zg16_ctx* ctx, const zg16_r1cs* r, const uint64_t* z_in, const uint64_t* z_aux, int on_device,
+                          Fr** z_out);
+zg16_status check_key_fits(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1cs* r);
 void pk_destroy(zg16_pk* pk);
+zg16_status pk_upload_impl(zg16_ctx* ctx, const zg16_pk_view* v, int shard_index, int shard_count, bool h_cyclic,
+                           zg16_pk** out);
 void r1cs_destroy(zg16_r1cs* r);
 }  // namespace zg
 

@@ -6,72 +6,215 @@
 // packing rows of ~250 terms (zinc-vm/src/gadgets/scalar/mod.rs:298-300), so short rows get one
 // lane each and long rows get one wavefront each; the split is fixed at upload time because the
 // matrices do not depend on the witness.
+//
+// Coefficients are not kept as 32-byte field elements.  zinc's gadgets emit +-1 and +-2^k almost
+// exclusively (zinc-vm/src/gadgets/scalar/mod.rs:298-300 for the powers of two), so a term is a
+// 4-byte variable index and a 2-byte coefficient CODE into a small table: code 0 adds z, code 1
+// subtracts it (upstream's `eval` skips the product for a coefficient of one; the result is the same
+// field value either way), every other code multiplies by a table entry that stays in cache.  A term
+// costs 6 bytes of matrix traffic instead of 36.
+#include <string.h>
+
+#include <unordered_map>
+
 #include "r1cs.cuh"
 
 namespace zg {
 
-ZG_D bool is_mont_one(const Fr& c) {
-  uint32_t o = 0;
-#pragma unroll
-  for (int i = 0; i < 8; i++) o |= c.v[i] ^ FrParams::one(i);
-  return o == 0;
+// ---- coefficient codes (host, at upload) ------------------------------------------------------------
+namespace {
+struct FrKey {
+  uint64_t w[4];
+  bool operator==(const FrKey& o) const { return w[0] == o.w[0] && w[1] == o.w[1] && w[2] == o.w[2] && w[3] == o.w[3]; }
+};
+struct FrKeyHash {
+  size_t operator()(const FrKey& k) const {
+    uint64_t h = k.w[0] * 0x9e3779b97f4a7c15ull;
+    h ^= (k.w[1] + 0xc2b2ae3d27d4eb4full) * 0xff51afd7ed558ccdull;
+    h ^= (k.w[2] << 17) ^ (k.w[3] * 0xc4ceb9fe1a85ec53ull);
+    return (size_t)(h ^ (h >> 29));
+  }
+};
+FrKey key_of(const Fr& f) {
+  FrKey k;
+  memcpy(k.w, f.v, 32);
+  return k;
+}
+}  // namespace
+
+// codes[e] for every coefficient and the table the codes index.  Table layout: [0] one, [1] minus one,
+// [2 + k] = 2^(k+1) and [256 + k] = -2^(k+1) for k < 253, [SPMV_CODE_DICT + i] = the i-th other value in order of
+// first appearance.  A matrix with more distinct other values than fit gets SPMV_CODE_FULL for the overflow and
+// keeps its full coefficient array for those terms (*needs_full).
+void spmv_encode_coeffs(const uint64_t* coeff, size_t nnz, std::vector<uint16_t>& codes, std::vector<Fr>& table,
+                        bool* needs_full) {
+  table.assign(SPMV_CODE_DICT, Fr::zero());
+  std::unordered_map<FrKey, uint16_t, FrKeyHash> known;
+  known.reserve(1024);
+  const Fr one = Fr::one(), minus_one = neg(one);
+  table[0] = one;
+  table[1] = minus_one;
+  known[key_of(one)] = 0;
+  known[key_of(minus_one)] = 1;
+  Fr p = one;
+  for (uint32_t k = 0; k < 253; k++) {
+    p = dbl(p);  // 2^(k+1) in Montgomery form; below r for every k < 253
+    table[2 + k] = p;
+    table[256 + k] = neg(p);
+    known.emplace(key_of(p), (uint16_t)(2 + k));
+    known.emplace(key_of(table[256 + k]), (uint16_t)(256 + k));
+  }
+  codes.resize(nnz);
+  *needs_full = false;
+  FrKey last = key_of(one);
+  uint16_t last_code = 0;
+  for (size_t e = 0; e < nnz; e++) {
+    FrKey k;
+    memcpy(k.w, coeff + 4 * e, 32);
+    if (k == last) {  // runs of equal coefficients (the ones of boolean rows) skip the table look-up
+      codes[e] = last_code;
+      continue;
+    }
+    uint16_t code;
+    auto it = known.find(k);
+    if (it != known.end()) {
+      code = it->second;
+    } else if (table.size() < SPMV_CODE_FULL) {
+      code = (uint16_t)table.size();
+      Fr f;
+      memcpy(f.v, k.w, 32);
+      table.push_back(f);
+      known.emplace(k, code);
+    } else {
+      code = SPMV_CODE_FULL;
+      *needs_full = true;
+    }
+    codes[e] = code;
+    last = k;
+    last_code = code;
+  }
 }
 
-ZG_D Fr term(const Fr& coeff, const Fr& z) {
-  // multiplying by the Montgomery form of one is the identity map: skip it
-  return is_mont_one(coeff) ? z : mul(coeff, z);
+// ---- kernels ------------------------------------------------------------------------------------------
+struct SpmvMatrix {
+  const uint32_t* row_ptr;
+  const uint32_t* col;
+  const uint16_t* code;
+  const Fr* table;
+  const Fr* coeff_full;  // only read for SPMV_CODE_FULL terms
+};
+
+// Which rows a launch evaluates and where their results go: output slot j holds row
+//   (j >> log_blk) * stride + base + (j & (2^log_blk - 1))
+// -- every row in order (log_blk = 31, base = 0), or the blocks of rows one GPU owns when a proof's transforms are
+// spread over several GPUs.  Rows at or beyond n_rows (the padding up to the domain size) evaluate to zero.
+struct RowMap {
+  uint32_t log_blk, stride, base, n_out, n_rows;
+  ZG_D uint32_t row(uint32_t j) const { return (j >> log_blk) * stride + base + (j & ((1u << log_blk) - 1)); }
+  // slot of row r, or 0xffffffff when this launch does not own it
+  ZG_D uint32_t slot(uint32_t r) const {
+    if (log_blk >= 31) return r;
+    if (r < base) return 0xffffffffu;
+    const uint32_t off = r - base, k = off / stride, rem = off - k * stride;
+    if (rem >> log_blk) return 0xffffffffu;
+    const uint32_t j = (k << log_blk) + rem;
+    return j < n_out ? j : 0xffffffffu;
+  }
+};
+
+ZG_D Fr add_term(const Fr& acc, const SpmvMatrix& m, uint32_t e, const Fr* __restrict__ z) {
+  const uint32_t code = m.code[e];
+  const Fr x = z[m.col[e]];
+  if (code == 0) return add(acc, x);
+  if (code == 1) return sub(acc, x);
+  const Fr c = code == SPMV_CODE_FULL ? m.coeff_full[e] : m.table[code];
+  return add(acc, mul(c, x));
 }
 
-__global__ __launch_bounds__(256) void k_spmv_short(const uint32_t* __restrict__ row_ptr,
-                                                    const uint32_t* __restrict__ col,
-                                                    const Fr* __restrict__ coeff, const Fr* __restrict__ z,
-                                                    Fr* __restrict__ out, uint32_t n_rows) {
-  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= n_rows) return;
-  const uint32_t lo = row_ptr[r], hi = row_ptr[r + 1];
-  if (hi - lo > SPMV_LONG_ROW) return;  // a wavefront takes this row in k_spmv_long
+// One launch evaluates up to three matrices (blockIdx.y picks one): A, B and C of a proof share the witness and
+// the row map, and three short launches in a row cost more in launch gaps and tails than in work.
+struct SpmvBatch {
+  SpmvMatrix m[3];
+  Fr* out[3];
+  const uint32_t* long_rows[3];
+  uint32_t n_long[3];
+};
+
+__global__ __launch_bounds__(256) void k_spmv_short(SpmvBatch batch, const Fr* __restrict__ z, RowMap map) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= map.n_out) return;
+  const SpmvMatrix& m = batch.m[blockIdx.y];
+  const uint32_t r = map.row(j);
   Fr acc = Fr::zero();
-  for (uint32_t k = lo; k < hi; k++) acc = add(acc, term(coeff[k], z[col[k]]));
-  out[r] = acc;
+  if (r < map.n_rows) {
+    const uint32_t lo = m.row_ptr[r], hi = m.row_ptr[r + 1];
+    if (hi - lo > SPMV_LONG_ROW) return;  // a wavefront takes this row in k_spmv_long
+    for (uint32_t e = lo; e < hi; e++) acc = add_term(acc, m, e, z);
+  }
+  batch.out[blockIdx.y][j] = acc;
 }
 
-__global__ __launch_bounds__(256) void k_spmv_long(const uint32_t* __restrict__ long_rows, uint32_t n_long,
-                                                   const uint32_t* __restrict__ row_ptr,
-                                                   const uint32_t* __restrict__ col,
-                                                   const Fr* __restrict__ coeff, const Fr* __restrict__ z,
-                                                   Fr* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_spmv_long(SpmvBatch batch, const Fr* __restrict__ z, RowMap map) {
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-  if (wave >= n_long) return;
-  const uint32_t r = long_rows[wave];
-  const uint32_t lo = row_ptr[r], hi = row_ptr[r + 1];
+  if (wave >= batch.n_long[blockIdx.y]) return;
+  const SpmvMatrix& m = batch.m[blockIdx.y];
+  const uint32_t r = batch.long_rows[blockIdx.y][wave];
+  const uint32_t j = map.slot(r);
+  if (j == 0xffffffffu) return;
+  const uint32_t lo = m.row_ptr[r], hi = m.row_ptr[r + 1];
   Fr acc = Fr::zero();
-  for (uint32_t k = lo + lane; k < hi; k += 64) acc = add(acc, term(coeff[k], z[col[k]]));
+  for (uint32_t e = lo + lane; e < hi; e += 64) acc = add_term(acc, m, e, z);
   for (int d = 32; d >= 1; d >>= 1) {
     Fr o;
 #pragma unroll
     for (int i = 0; i < 8; i++) o.v[i] = __shfl_down(acc.v[i], d);
     acc = add(acc, o);
   }
-  if (lane == 0) out[r] = acc;
+  if (lane == 0) batch.out[blockIdx.y][j] = acc;
 }
 
-zg16_status spmv_one_device(zg16_ctx* ctx, const zg16_r1cs* r, int k, const Fr* z, Fr* out) {
+// matrices first .. first + count - 1 into outs[0 .. count)
+static zg16_status spmv_launch(zg16_ctx* ctx, const zg16_r1cs* r, int first, int count, const Fr* z, Fr* const* outs,
+                               const RowMap& map) {
   hipStream_t st = ctx->stream;
-  const R1csMatrix& m = r->m[k];
-  KernelTimer kt(ctx, K_SPMV, (double)m.nnz * 36 + (double)(r->n_in + r->n_aux) * 32 + (double)r->n_rows * 36);
-  if (r->n_rows)
-    k_spmv_short<<<(unsigned)((r->n_rows + 255) / 256), 256, 0, st>>>(m.row_ptr, m.col, m.coeff, z, out,
-                                                                      (uint32_t)r->n_rows);
-  if (m.n_long)
-    k_spmv_long<<<(unsigned)((m.n_long + 3) / 4), 256, 0, st>>>(m.long_rows, m.n_long, m.row_ptr, m.col, m.coeff, z, out);
+  SpmvBatch batch = {};
+  uint32_t max_long = 0;
+  double nnz = 0;
+  for (int k = 0; k < count; k++) {
+    const R1csMatrix& m = r->m[first + k];
+    batch.m[k] = {m.row_ptr, m.col, m.code, m.table, m.coeff};
+    batch.out[k] = outs[k];
+    batch.long_rows[k] = m.long_rows;
+    batch.n_long[k] = m.n_long;
+    max_long = m.n_long > max_long ? m.n_long : max_long;
+    nnz += (double)m.nnz;
+  }
+  const double share = r->n_rows ? (double)map.n_out / (double)(map.log_blk >= 31 ? r->n_rows : ((size_t)1 << r->log_m)) : 0.0;
+  KernelTimer kt(ctx, K_SPMV, share * (nnz * 36 + (double)count * r->n_rows * 36) + (double)count * (r->n_in + r->n_aux) * 32);
+  if (map.n_out) k_spmv_short<<<dim3((map.n_out + 255) / 256, count), 256, 0, st>>>(batch, z, map);
+  if (max_long) k_spmv_long<<<dim3((max_long + 3) / 4, count), 256, 0, st>>>(batch, z, map);
   ZG_HIP(ctx, hipGetLastError());
   return ZG16_OK;
 }
 
+zg16_status spmv_one_device(zg16_ctx* ctx, const zg16_r1cs* r, int k, const Fr* z, Fr* out) {
+  const RowMap all = {31, 0, 0, (uint32_t)r->n_rows, (uint32_t)r->n_rows};
+  return spmv_launch(ctx, r, k, 1, z, &out, all);
+}
+
 zg16_status spmv_device(zg16_ctx* ctx, const zg16_r1cs* r, const Fr* z, Fr* a, Fr* b, Fr* c) {
-  Fr* outs[3] = {a, b, c};
-  for (int k = 0; k < 3; k++) ZG_TRY(spmv_one_device(ctx, r, k, z, outs[k]));
-  return ZG16_OK;
+  Fr* const outs[3] = {a, b, c};
+  const RowMap all = {31, 0, 0, (uint32_t)r->n_rows, (uint32_t)r->n_rows};
+  return spmv_launch(ctx, r, 0, 3, z, outs, all);
+}
+
+// Rows (j >> log_blk) * stride + base + (j mod 2^log_blk), j < n_out, of all three matrices into a, b, c; padding
+// rows give zero.
+zg16_status spmv_blocks_device(zg16_ctx* ctx, const zg16_r1cs* r, const Fr* z, Fr* a, Fr* b, Fr* c, uint32_t log_blk,
+                               uint32_t stride, uint32_t base, uint32_t n_out) {
+  Fr* const outs[3] = {a, b, c};
+  const RowMap map = {log_blk, stride, base, n_out, (uint32_t)r->n_rows};
+  return spmv_launch(ctx, r, 0, 3, z, outs, map);
 }
 
 }  // namespace zg

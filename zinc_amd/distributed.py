@@ -121,6 +121,58 @@ def prove_sharded(ctx, key, mat, z_in_ptr, z_aux_ptr, on_device, pk_view, r_mont
     return finish(pk_view, parts, world, r_mont, s_mont)
 
 
+# ---- transforms sharded through the whole H computation ----------------------------------------------
+class ShardedProver:
+    """One rank of a proof whose transforms are spread over the GPUs as well (zg16_hshard_*): this rank's key
+    shard (h cyclic, the other queries by point range), its stage object and its two exchange buffers."""
+
+    def __init__(self, ctx, params, mat, rank, world, device):
+        import torch
+        self.ctx, self.mat, self.rank, self.world, self.device = ctx, mat, rank, world, device
+        self.log_g = world.bit_length() - 1
+        assert 1 << self.log_g == world and 2 <= world <= 8, "2, 4 or 8 ranks"
+        L = ctx._lib
+        self.pk_view = params.view()
+        self.key = C.c_void_p()
+        _check(ctx.handle, L.zg16_pk_upload_cyclic_h(ctx.handle, C.byref(self.pk_view), rank, world, C.byref(self.key)))
+        self.hs = C.c_void_p()
+        _check(ctx.handle, L.zg16_hshard_create(ctx.handle, self.key, mat.handle, self.log_g, rank, C.byref(self.hs)))
+        self.rows = L.zg16_hshard_vector_bytes(self.hs) // 32
+        self.work = torch.empty((3, self.rows, 4), dtype=torch.int64, device=device)
+        self.got = torch.empty((3, self.rows, 4), dtype=torch.int64, device=device)
+
+    def prove(self, z_in_ptr, z_aux_ptr, on_device, r_mont, s_mont):
+        """Returns the lib.Proof on rank 0 and None elsewhere."""
+        L = self.ctx._lib
+        n = C.c_int()
+        for stage in range(4):
+            _check(self.ctx.handle, L.zg16_hshard_stage(self.hs, stage, C.c_void_p(z_in_ptr), C.c_void_p(z_aux_ptr),
+                                                        int(on_device), C.c_void_p(self.work.data_ptr()),
+                                                        C.c_void_p(self.got.data_ptr()), C.byref(n)))
+            for v in range(n.value):
+                # (with gloo the exchange is staged through the host and lands back in the source tensor)
+                self.got[v].copy_(_all_to_all(self.work[v], self.world, self.device))
+            if n.value:
+                # the library's kernels run on its own streams: torch's copies must have landed before the next stage
+                import torch
+                torch.cuda.synchronize(self.device)
+        part = _lib.Partial()
+        _check(self.ctx.handle, L.zg16_hshard_finish(self.hs, C.byref(part)))
+        parts = gather_partials(part, self.world, self.rank, self.device)
+        if self.rank != 0:
+            return None
+        return finish(self.pk_view, parts, self.world, r_mont, s_mont)
+
+    def free(self):
+        L = self.ctx._lib
+        if self.hs:
+            L.zg16_hshard_free(self.hs)
+            self.hs = C.c_void_p()
+        if self.key:
+            L.zg16_pk_free(self.key)
+            self.key = C.c_void_p()
+
+
 # ---- one transform over several GPUs --------------------------------------------------------------
 def ntt_shard_input(x, rank, world):
     """Rank `rank`'s part of a natural-order vector x (rows = elements): x[rank + world * j]."""

@@ -418,6 +418,53 @@ class ProvingAssignment:
         return zi, za
 
 
+class MultiProver:
+    """zg16_multi_*: several GPUs driven from this one process (a context and a host thread per GPU, peer copies
+    for the exchanges).  devices may repeat an index: several contexts on one GPU rehearse the schedule."""
+
+    def __init__(self, devices):
+        self._lib = _lib.load()
+        self.handle = C.c_void_p()
+        ids = (C.c_int * len(devices))(*devices)
+        st = self._lib.zg16_multi_create(ids, len(devices), C.byref(self.handle))
+        if st != _lib.OK:
+            raise SynthesisError(st, "cannot create contexts on GPUs %r" % (list(devices),))
+
+    def _check(self, st):
+        if st != _lib.OK:
+            raise SynthesisError(st, self._lib.zg16_multi_last_error(self.handle).decode())
+
+    def load(self, params, r1cs, sharded_transforms=None):
+        """Shard the key over the GPUs and upload the matrices to each.  sharded_transforms: True / False / None
+        (the library chooses).  Returns whether the transforms are sharded."""
+        pv, rv = params.view(), r1cs.view()
+        mode = -1 if sharded_transforms is None else int(bool(sharded_transforms))
+        self._check(self._lib.zg16_multi_load(self.handle, C.byref(pv), C.byref(rv), mode))
+        return bool(self._lib.zg16_multi_sharded_transforms(self.handle))
+
+    def prove(self, z_in, z_aux, r_mont, s_mont):
+        raw = _lib.Proof()
+        zi = np.ascontiguousarray(z_in, dtype=np.uint64).reshape(-1, 4)
+        za = np.ascontiguousarray(z_aux, dtype=np.uint64).reshape(-1, 4)
+        r_mont = np.ascontiguousarray(r_mont, dtype=np.uint64).reshape(4)
+        s_mont = np.ascontiguousarray(s_mont, dtype=np.uint64).reshape(4)
+        self._check(self._lib.zg16_multi_prove(self.handle, zi.ctypes.data_as(C.c_void_p),
+                                               za.ctypes.data_as(C.c_void_p) if za.size else None,
+                                               _lib.as_u64p(r_mont), _lib.as_u64p(s_mont), C.byref(raw)))
+        return Proof(raw)
+
+    def close(self):
+        if self.handle:
+            self._lib.zg16_multi_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class WitnessAssignment(ProvingAssignment):
     """Constraint system for a circuit whose matrices are already resident (DeviceR1CS.cached hit): it keeps the
     witness and drops every row, so synthesis pays for witness generation only.  bellman hands `enforce` three

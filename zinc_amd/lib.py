@@ -104,6 +104,19 @@ SYMBOLS = [
     ("zg16_r1cs_log_domain", C.c_uint, [C.c_void_p]),
     ("zg16_prove_finish", C.c_int, [C.POINTER(PkView), C.POINTER(Partial), C.c_size_t, u64p, u64p,
                                     C.POINTER(Proof)]),
+    ("zg16_pk_upload_cyclic_h", C.c_int, [C.c_void_p, C.POINTER(PkView), C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    ("zg16_hshard_create", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.POINTER(C.c_void_p)]),
+    ("zg16_hshard_free", None, [C.c_void_p]),
+    ("zg16_hshard_vector_bytes", C.c_size_t, [C.c_void_p]),
+    ("zg16_hshard_stage", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                    C.POINTER(C.c_int)]),
+    ("zg16_hshard_finish", C.c_int, [C.c_void_p, C.POINTER(Partial)]),
+    ("zg16_multi_create", C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
+    ("zg16_multi_destroy", None, [C.c_void_p]),
+    ("zg16_multi_last_error", C.c_char_p, [C.c_void_p]),
+    ("zg16_multi_load", C.c_int, [C.c_void_p, C.POINTER(PkView), C.POINTER(R1csView), C.c_int]),
+    ("zg16_multi_sharded_transforms", C.c_int, [C.c_void_p]),
+    ("zg16_multi_prove", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, u64p, u64p, C.POINTER(Proof)]),
     ("zg16_ntt", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint, C.c_int, C.c_int, C.c_int]),
     ("zg16_h_coefficients", C.c_int, [C.c_void_p, u64p, u64p, u64p, C.c_size_t, u64p, C.POINTER(C.c_size_t)]),
     ("zg16_msm_g1", C.c_int, [C.c_void_p, u64p, C.c_size_t, u64p, C.c_size_t, u8p, u64p]),
