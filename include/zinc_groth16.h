@@ -39,7 +39,8 @@ typedef enum {
   ZG16_ERR_MALFORMED_KEY = 4,               /* key vector lengths do not fit the circuit      */
   ZG16_ERR_INVALID_ARGUMENT = 5,
   ZG16_ERR_DEVICE = 6,                      /* a HIP call failed; see zg16_last_error         */
-  ZG16_ERR_OUT_OF_MEMORY = 7
+  ZG16_ERR_OUT_OF_MEMORY = 7,
+  ZG16_ERR_UNCONSTRAINED_VARIABLE = 8       /* key generation: an aux variable occurs in no row */
 } zg16_status;
 
 typedef struct zg16_ctx zg16_ctx;   /* one GPU, its streams and scratch memory */
@@ -344,6 +345,32 @@ zg16_status zg16_fixed_base_g1(zg16_ctx* ctx, const uint64_t base[8], const uint
                                uint64_t* out);
 zg16_status zg16_fixed_base_g2(zg16_ctx* ctx, const uint64_t base[16], const uint64_t* scalars, size_t n,
                                uint64_t* out);
+
+/* bellman `generate_parameters(circuit, g1, g2, alpha, beta, gamma, delta, tau)` -- what
+ * `generate_random_parameters` runs after drawing those values (zinc-vm/src/core/circuit/facade.rs:126,
+ * core/contract/facade.rs:299) -- on the GPU: the Lagrange values L_j(tau) by one inverse transform, the per-variable
+ * sums A_v(tau), B_v(tau), C_v(tau) as a sparse product with the transposed matrices, and every key point by
+ * fixed-base multiplication.  `circuit` holds the rows as for proving (the `input_i * 0 = 0` rows appended; the
+ * coefficients are structure, no witness is involved).  Scalars are Montgomery Fr, g1 / g2 affine points.
+ * The caller allocates the output arrays: ic n_inputs points, h m - 1 (m = the domain size, next power of two
+ * >= n_rows), l n_aux, a / b_g1 / b_g2 n_inputs + n_aux (capacity; n_a and n_b receive the counts after the
+ * identities are dropped, as upstream drops them).  ZG16_ERR_UNCONSTRAINED_VARIABLE mirrors
+ * SynthesisError::UnconstrainedVariable. */
+typedef struct {
+  uint64_t g1[8], g2[16];
+  uint64_t alpha[4], beta[4], gamma[4], delta[4], tau[4];
+} zg16_toxic_waste;
+typedef struct {
+  uint64_t alpha_g1[8], beta_g1[8], beta_g2[16], gamma_g2[16], delta_g1[8], delta_g2[16];
+  uint64_t* ic;
+  uint64_t* h;
+  uint64_t* l;
+  uint64_t* a;    size_t n_a;
+  uint64_t* b_g1;
+  uint64_t* b_g2; size_t n_b;
+} zg16_parameters_out;
+zg16_status zg16_generate_parameters(zg16_ctx* ctx, const zg16_r1cs_view* circuit, const zg16_toxic_waste* toxic,
+                                     zg16_parameters_out* out);
 
 /* ---- timing of the last zg16_prove / zg16_prove_partial on this context -------------------- */
 typedef struct {

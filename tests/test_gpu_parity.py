@@ -845,3 +845,71 @@ def test_multi_gpu_prover_errors(gpu_ctx):
         mp.prove(zi, za, rs[0], rs[1])
     assert e.value.status_name == "UnexpectedIdentity"
     mp.close()
+
+
+# ------------------------------------------------------------------------------ key generation
+@pytest.mark.gpu
+@pytest.mark.parametrize("idx", [1, 2, 3])
+def test_generate_parameters_golden(gpu_ctx, idx):
+    """zg16_generate_parameters from the fixture's toxic waste gives the fixture's key, point for point
+    (bellman `generate_parameters`: Lagrange values, per-variable sums, identity points dropped from a / b)."""
+    from zinc_amd import workload
+    fx = golden("prove_tiny_%d.json" % idx)
+    circ, key = FixtureCircuit(fx), FixtureKey(fx)
+    pa = ProvingAssignment()
+    pa.alloc_input(1)
+    circ.synthesize(pa)
+    pa.finalize_inputs()
+    got = workload.generate_parameters(gpu_ctx, pa.r1cs(), {k: int(v, 16) for k, v in fx["toxic"].items()})
+    want = Parameters.from_points(key)
+    for name in ("alpha_g1", "beta_g1", "beta_g2", "delta_g1", "delta_g2", "h", "l", "a", "b_g1", "b_g2"):
+        assert np.array_equal(getattr(got, name), getattr(want, name)), name
+    assert np.array_equal(got.ic, g1_to_mont(key.ic)) and np.array_equal(got.gamma_g2, g2_to_mont([key.gamma_g2]))
+
+
+@pytest.mark.gpu
+def test_generate_parameters_vs_host_and_unconstrained(gpu_ctx):
+    from zinc_amd import workload
+    circ = workload.SyntheticCircuit(1 << 13, n_pub=5, seed=(4, 3, 2, 1))
+    toxic = dict(k1=5, k2=7, alpha=11, beta=13, gamma=17, delta=19, tau=0x1234567)
+    got = workload.generate_parameters(gpu_ctx, circ, toxic)
+    want = workload.generate_parameters_host(gpu_ctx, circ, toxic)
+    for name in ("alpha_g1", "beta_g1", "beta_g2", "delta_g1", "delta_g2", "gamma_g2", "ic", "h", "l", "a", "b_g1", "b_g2"):
+        assert np.array_equal(getattr(got, name), getattr(want, name)), name
+    # an aux variable that no row mentions: bellman's UnconstrainedVariable
+    pa = ProvingAssignment()
+    pa.alloc_input(1)
+    x, y = pa.alloc(3), pa.alloc(4)
+    pa.enforce([(x, 1)], [(x, 1)], [(0, 9)])
+    pa.finalize_inputs()
+    with pytest.raises(SynthesisError) as e:
+        workload.generate_parameters(gpu_ctx, pa.r1cs(), toxic)
+    assert e.value.status_name == "UnconstrainedVariable"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,storage_root", [(5, None), (6, None), (7, None), (6, 0x1234567890abcdef << 100)])
+def test_factorial_stand_in_proves_and_verifies(gpu_ctx, n, storage_root):
+    """A zinc-tester-sized circuit (hand-recorded factorial.zn; with a storage root appended it has the shape of a
+    contract method's): key from zg16_generate_parameters, proof bit-identical to the CPU restatement, and it
+    verifies against the public inputs the reference's test pins (proof_check.rs:243-264: verify == true)."""
+    from oracle import cpu_binding as cb
+    from oracle import groth16 as G
+    from zinc_amd import standin, workload
+    circ = standin.FactorialCircuit(n, storage_root)
+    pa = standin.record(circ)
+    assert circ.result == standin.FactorialCircuit.CASES[n]
+    r1cs = pa.r1cs()
+    params = workload.generate_parameters(gpu_ctx, r1cs, dict(k1=3, k2=5, alpha=7, beta=11, gamma=13, delta=17, tau=0xFAC70))
+    zi, za = pa.witness()
+    rs = ints_to_mont([0x5EED, 0xFEED], R_MOD)
+    st, want, _ = cb.prove(params, r1cs, zi, za, rs[0], rs[1], threads=4)
+    assert st == 0
+    key, hit = params.cached(gpu_ctx)
+    mat, _ = r1cs.cached(gpu_ctx, b"factorial.zn/main" + (b"+root" if storage_root is not None else b""))
+    got = prove_recorded(gpu_ctx, key, mat, zi, za, rs[0], rs[1])
+    for g, w in zip((got.raw.a, got.raw.b, got.raw.c), want):
+        assert np.array_equal(np.frombuffer(bytes(g), dtype=np.uint64), w)
+    public = circ.public_inputs()
+    assert G.verify_proof(_vk_of(params), got.as_tuple(), public)
+    assert not G.verify_proof(_vk_of(params), got.as_tuple(), [public[0] + 1] + public[1:])

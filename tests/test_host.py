@@ -255,3 +255,36 @@ def test_proof_encode_matches_codec_and_fixtures():
     out = (C.c_uint8 * 128)()
     assert L.zg16_proof_encode(C.byref(raw), out) == 0
     assert bytes(out).hex() == codec.proof_write((na, nb, None)).hex()
+
+
+@pytest.mark.parametrize("n", [5, 6, 7, 0, 200])
+def test_factorial_stand_in_rows(n):
+    """The hand-recorded factorial.zn circuit: the output is the reference's pinned one
+    (zinc-tester/tests/algorithm/factorial.zn: 5 -> 120, 6 -> 720, 7 -> 5040), every row is satisfied, and every
+    linear combination is in zinc-vm's canonical form (constraint_systems/dedup.rs:30-69)."""
+    from zinc_amd import standin
+    from zinc_amd.fields import R_MOD
+    import math
+    circ = standin.FactorialCircuit(n)
+    pa = standin.record(circ)
+    want = standin.FactorialCircuit.CASES.get(n, math.factorial(min(n, 7)))
+    assert circ.result == want and pa.z_in == [1, want]
+    z = lambda v: pa.z_aux[v & 0x7fffffff] if v & (1 << 31) else pa.z_in[v]
+    n_rows = len(pa._rp[0]) - 1
+    assert 1500 < n_rows < 2048    # a factorial.zn-sized circuit: domain 2^11
+    for r in range(n_rows):
+        vals = []
+        for k in range(3):
+            lo, hi = pa._rp[k][r], pa._rp[k][r + 1]
+            cols = pa._col[k][lo:hi]
+            key = [((c >> 31), c & 0x7fffffff) for c in cols]
+            assert key == sorted(set(key)), "row %d matrix %d is not canonical" % (r, k)
+            assert all(pa._coeff[k][lo:hi])
+            vals.append(sum(co * z(c) for c, co in zip(cols, pa._coeff[k][lo:hi])) % R_MOD)
+        assert vals[0] * vals[1] % R_MOD == vals[2], "row %d is not satisfied" % r
+    # every aux variable occurs in some row (bellman's setup refuses the circuit otherwise)
+    seen = {c for k in range(3) for c in pa._col[k] if c & (1 << 31)}
+    assert len(seen) == len(pa.z_aux)
+    # the matrices do not depend on the input: that is what lets a prover keep them resident per (bytecode, method)
+    other = standin.record(standin.FactorialCircuit(3))
+    assert other._rp == pa._rp and other._col == pa._col and other._coeff == pa._coeff

@@ -67,6 +67,14 @@ __global__ __launch_bounds__(256) void k_pow_table(Fr* out, uint32_t count, Fr b
   }
 }
 
+// out[i] = c * base^i for i < count, device memory, on the context's stream
+zg16_status pow_table_device(zg16_ctx* ctx, Fr* out, size_t count, const Fr& base, const Fr& c) {
+  if (!count) return ZG16_OK;
+  k_pow_table<<<(unsigned)((count + 4095) / 4096), 256, 0, ctx->stream>>>(out, (uint32_t)count, base, c);
+  ZG_HIP(ctx, hipGetLastError());
+  return ZG16_OK;
+}
+
 // ABI-form table -> Fr29 table (radix change by one product)
 __global__ __launch_bounds__(256) void k_to_fr29(const Fr* __restrict__ in, Fr29* __restrict__ out, uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -9,8 +9,10 @@
 // mixed additions and converts its own result to affine.
 #include <string.h>
 
+#include <vector>
+
 #define ZG_OUTLINE_FIELD_MUL 1
-#include "common.cuh"
+#include "r1cs.cuh"
 
 namespace zg {
 
@@ -49,31 +51,210 @@ __global__ __launch_bounds__(256) void k_fb_mul(const Affine<F>* __restrict__ ta
   out[i] = to_affine(acc);
 }
 
+// d_scalars: n Montgomery Fr in device memory (not inside scratch arena 5); out: n affine points in host memory.
+template <class F>
+static zg16_status fixed_base_device(zg16_ctx* ctx, const Affine<F>& b, const Fr* d_scalars, size_t n, void* out) {
+  if (n >= 0xffffffffull) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "too many scalars");
+  if (!n) return ZG16_OK;
+  const int tn = FB_WINDOWS * FB_DIGITS;
+  char* buf;
+  const size_t t_x = (size_t)tn * sizeof(XYZZ<F>), t_a = (size_t)tn * sizeof(Affine<F>), o_b = n * sizeof(Affine<F>);
+  ZG_TRY(scratch_get(ctx, 5, t_x + t_a + o_b + 1024, (void**)&buf));
+  XYZZ<F>* tx = (XYZZ<F>*)buf;
+  Affine<F>* ta = (Affine<F>*)(buf + t_x);
+  Affine<F>* dout = (Affine<F>*)(buf + t_x + t_a);
+  hipStream_t st = ctx->stream;
+  k_fb_table_rows<F><<<1, 64, 0, st>>>(b, tx);
+  k_fb_table_affine<F><<<(tn + 255) / 256, 256, 0, st>>>(tx, ta, tn);
+  k_fb_mul<F><<<(unsigned)((n + 255) / 256), 256, 0, st>>>(ta, d_scalars, dout, (uint32_t)n);
+  ZG_HIP(ctx, hipGetLastError());
+  ZG_HIP(ctx, hipMemcpyAsync(out, dout, o_b, hipMemcpyDeviceToHost, st));
+  ZG_HIP(ctx, hipStreamSynchronize(st));
+  return ZG16_OK;
+}
+
 template <class F>
 static zg16_status fixed_base(zg16_ctx* ctx, const uint64_t* base, const uint64_t* scalars, size_t n, uint64_t* out) {
   if (!ctx || !base || (n && (!scalars || !out))) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "bad arguments to fixed-base multiply");
-  if (n >= 0xffffffffull) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "too many scalars");
   if (!n) return ZG16_OK;
   ZG_HIP(ctx, hipSetDevice(ctx->device));
   Affine<F> b;
   memcpy(&b, base, sizeof b);
-  const int tn = FB_WINDOWS * FB_DIGITS;
-  char* buf;
-  const size_t t_x = (size_t)tn * sizeof(XYZZ<F>), t_a = (size_t)tn * sizeof(Affine<F>);
-  const size_t s_b = n * sizeof(Fr), o_b = n * sizeof(Affine<F>);
-  ZG_TRY(scratch_get(ctx, 5, t_x + t_a + s_b + o_b + 1024, (void**)&buf));
-  XYZZ<F>* tx = (XYZZ<F>*)buf;
-  Affine<F>* ta = (Affine<F>*)(buf + t_x);
-  Fr* ds = (Fr*)(buf + t_x + t_a);
-  Affine<F>* dout = (Affine<F>*)(buf + t_x + t_a + ((s_b + 255) & ~(size_t)255));
-  hipStream_t st = ctx->stream;
-  ZG_HIP(ctx, hipMemcpyAsync(ds, scalars, s_b, hipMemcpyHostToDevice, st));
-  k_fb_table_rows<F><<<1, 64, 0, st>>>(b, tx);
-  k_fb_table_affine<F><<<(tn + 255) / 256, 256, 0, st>>>(tx, ta, tn);
-  k_fb_mul<F><<<(unsigned)((n + 255) / 256), 256, 0, st>>>(ta, ds, dout, (uint32_t)n);
+  Fr* ds;
+  ZG_TRY(scratch_get(ctx, 7, n * sizeof(Fr), (void**)&ds));
+  ZG_HIP(ctx, hipMemcpyAsync(ds, scalars, n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+  return fixed_base_device<F>(ctx, b, ds, n, out);
+}
+
+// ---- the field half of key generation ------------------------------------------------------------------
+// bellman_ce 0.3.0 `generate_parameters` (the reference calls `generate_random_parameters` at
+// zinc-vm/src/core/circuit/facade.rs:126 and core/contract/facade.rs:299): with L_j(tau) the Lagrange values of the
+// m-point domain (the inverse transform of the powers of tau), every variable v gets
+//   a_v = sum over A's entries (row, v) of coeff * L_row(tau),  b_v, c_v likewise,
+// i.e. the TRANSPOSED matrices times the vector L -- the same sparse mat-vec as the prover's row evaluation, on
+// the transposed structure.  Then ic_v / l_v = (beta a_v + alpha b_v + c_v) / gamma (inputs) or / delta (aux), the
+// h scalars tau^i (tau^m - 1) / delta, and every key point is one of those scalars times g1 or g2.
+
+// out[v] = (beta a[v] + alpha b[v] + c[v]) * (v < n_in ? gamma_inv : delta_inv)
+__global__ __launch_bounds__(256) void k_setup_combine(const Fr* __restrict__ a, const Fr* __restrict__ b,
+                                                       const Fr* __restrict__ c, Fr* __restrict__ out, uint32_t nv,
+                                                       uint32_t n_in, Fr alpha, Fr beta, Fr gamma_inv, Fr delta_inv) {
+  const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nv) return;
+  const Fr t = add(add(mul(beta, a[v]), mul(alpha, b[v])), c[v]);
+  out[v] = mul(t, v < n_in ? gamma_inv : delta_inv);
+}
+
+// The transpose of one CSR matrix as a device-resident R1csMatrix whose "rows" are the variables (inputs then aux)
+// and whose "columns" are the constraint rows.
+static zg16_status upload_transposed(zg16_ctx* ctx, const zg16_csr& m, size_t n_rows, size_t n_in, size_t n_aux, int which,
+                                     R1csMatrix* out) {
+  const size_t nv = n_in + n_aux;
+  if (!m.row_ptr) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "matrix %d has no row_ptr", which);
+  const size_t nnz = (size_t)m.row_ptr[n_rows];
+  if (nnz >= 0xffffffffull) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "matrix %d has too many entries", which);
+  if (nnz && (!m.col || !m.coeff)) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "matrix %d has no col/coeff", which);
+  std::vector<uint32_t> vp(nv + 1, 0), rows(nnz), longs;
+  std::vector<uint64_t> co(4 * nnz);
+  auto flat = [&](uint32_t c, size_t* v) {
+    const bool aux = (c & 0x80000000u) != 0;
+    const size_t i = c & 0x7fffffffu;
+    if (i >= (aux ? n_aux : n_in)) return false;
+    *v = aux ? n_in + i : i;
+    return true;
+  };
+  for (size_t e = 0; e < nnz; e++) {
+    size_t v;
+    if (!flat(m.col[e], &v)) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "matrix %d names a variable the circuit does not have", which);
+    vp[v + 1]++;
+  }
+  for (size_t v = 0; v < nv; v++) {
+    if (vp[v + 1] > SPMV_LONG_ROW) longs.push_back((uint32_t)v);
+    vp[v + 1] += vp[v];
+  }
+  std::vector<uint32_t> cursor(vp.begin(), vp.end() - 1);
+  for (size_t r = 0; r < n_rows; r++) {
+    if (m.row_ptr[r + 1] < m.row_ptr[r] || m.row_ptr[r + 1] > nnz) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "matrix %d row_ptr is not monotone", which);
+    for (uint64_t e = m.row_ptr[r]; e < m.row_ptr[r + 1]; e++) {
+      size_t v;
+      flat(m.col[e], &v);
+      const uint32_t pos = cursor[v]++;
+      rows[pos] = (uint32_t)r;
+      memcpy(&co[4 * (size_t)pos], m.coeff + 4 * e, 32);
+    }
+  }
+  std::vector<uint16_t> codes;
+  std::vector<Fr> table;
+  bool needs_full = false;
+  spmv_encode_coeffs(co.data(), nnz, codes, table, &needs_full);
+  auto up = [&](auto** dst, const auto* src, size_t count) -> zg16_status {
+    *dst = nullptr;
+    if (!count) return ZG16_OK;
+    ZG_HIP(ctx, hipMalloc((void**)dst, count * sizeof(**dst)));
+    ZG_HIP(ctx, hipMemcpy(*dst, src, count * sizeof(**dst), hipMemcpyHostToDevice));
+    return ZG16_OK;
+  };
+  out->nnz = nnz;
+  out->n_long = (uint32_t)longs.size();
+  out->n_table = (uint32_t)table.size();
+  ZG_TRY(up(&out->row_ptr, vp.data(), vp.size()));
+  ZG_TRY(up(&out->col, rows.data(), nnz));
+  ZG_TRY(up(&out->code, codes.data(), nnz));
+  ZG_TRY(up(&out->table, table.data(), table.size()));
+  ZG_TRY(up(&out->long_rows, longs.data(), longs.size()));
+  if (needs_full) ZG_TRY(up(&out->coeff, (const Fr*)co.data(), nnz));
+  return ZG16_OK;
+}
+
+// (this file outlines the device-side field product; host code reaches the product through a host/device wrapper)
+ZG_HD Fr mul_hd(const Fr& a, const Fr& b) { return mul(a, b); }
+
+static Fr load_fr4(const uint64_t* p) {
+  Fr r;
+  memcpy(r.v, p, 32);
+  return r;
+}
+
+static zg16_status generate_parameters(zg16_ctx* ctx, const zg16_r1cs_view* v, const zg16_toxic_waste* tw, zg16_parameters_out* out) {
+  const size_t n_in = v->n_inputs, n_aux = v->n_aux, nv = n_in + n_aux, n_rows = v->n_rows;
+  if (n_in < 1) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "n_inputs must include the constant ONE");
+  if (nv >= 0x7fffffffull) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "too many variables");
+  const unsigned log_m = ceil_log2(n_rows ? n_rows : 1);
+  if (log_m >= 28) return fail(ctx, ZG16_ERR_POLYNOMIAL_DEGREE_TOO_LARGE, "%zu rows need a domain of 2^%u", n_rows, log_m);
+  const size_t m = (size_t)1 << log_m;
+  if (!out->ic || (m > 1 && !out->h) || (n_aux && !out->l) || !out->a || !out->b_g1 || !out->b_g2)
+    return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "zg16_generate_parameters: an output array is missing");
+  ZG_HIP(ctx, hipSetDevice(ctx->device));
+  const Fr tau = load_fr4(tw->tau), alpha = load_fr4(tw->alpha), beta = load_fr4(tw->beta), gamma = load_fr4(tw->gamma),
+           delta = load_fr4(tw->delta);
+  if (gamma.is_zero() || delta.is_zero()) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "gamma and delta must be invertible");
+  const Fr gamma_inv = inv(gamma), delta_inv = inv(delta), one = Fr::one();
+  G1Affine g1;
+  G2Affine g2;
+  memcpy(&g1, tw->g1, sizeof g1);
+  memcpy(&g2, tw->g2, sizeof g2);
+
+  // transposed matrices (a temporary zg16_r1cs whose rows are the variables), released on every exit
+  std::unique_ptr<zg16_r1cs, void (*)(zg16_r1cs*)> t(new zg16_r1cs(), r1cs_destroy);
+  t->n_rows = nv;
+  t->n_in = m;  // (the "witness" of the transposed product is the vector L of m entries)
+  t->n_aux = 0;
+  t->log_m = ceil_log2(nv);
+  const zg16_csr* mats[3] = {&v->a, &v->b, &v->c};
+  for (int k = 0; k < 3; k++) ZG_TRY(upload_transposed(ctx, *mats[k], n_rows, n_in, n_aux, k, &t->m[k]));
+
+  // device work area: L (m), a_s, b_s, c_s, icl_s (nv each), h_s (m)
+  Fr* work = nullptr;
+  ZG_HIP(ctx, hipMalloc((void**)&work, (2 * m + 4 * nv) * sizeof(Fr)));
+  std::unique_ptr<Fr, void (*)(Fr*)> work_guard(work, [](Fr* p) { (void)hipFree(p); });
+  Fr *lag = work, *a_s = lag + m, *b_s = a_s + nv, *c_s = b_s + nv, *icl_s = c_s + nv, *h_s = icl_s + nv;
+  ZG_TRY(pow_table_device(ctx, lag, m, tau, one));
+  ZG_TRY(ntt_device(ctx, lag, log_m, true, false));  // L_j(tau)
+  ZG_TRY(spmv_device(ctx, t.get(), lag, a_s, b_s, c_s));
+  k_setup_combine<<<(unsigned)((nv + 255) / 256), 256, 0, ctx->stream>>>(a_s, b_s, c_s, icl_s, (uint32_t)nv, (uint32_t)n_in, alpha,
+                                                                       beta, gamma_inv, delta_inv);
+  // h[i] = g1 * tau^i (tau^m - 1) / delta
+  const Fr zt = mul_hd(sub(pow_u64(tau, (uint64_t)m), one), delta_inv);
+  ZG_TRY(pow_table_device(ctx, h_s, m - 1, tau, zt));
   ZG_HIP(ctx, hipGetLastError());
-  ZG_HIP(ctx, hipMemcpyAsync(out, dout, o_b, hipMemcpyDeviceToHost, st));
-  ZG_HIP(ctx, hipStreamSynchronize(st));
+
+  // every key point is a known scalar times g1 or g2
+  std::vector<G1Affine> pa(nv), pb1(nv);
+  std::vector<G2Affine> pb2(nv);
+  std::vector<G1Affine> icl(nv);
+  ZG_TRY(fixed_base_device<Fq>(ctx, g1, a_s, nv, pa.data()));
+  ZG_TRY(fixed_base_device<Fq>(ctx, g1, b_s, nv, pb1.data()));
+  ZG_TRY(fixed_base_device<Fq2>(ctx, g2, b_s, nv, pb2.data()));
+  ZG_TRY(fixed_base_device<Fq>(ctx, g1, icl_s, nv, icl.data()));
+  if (m > 1) ZG_TRY(fixed_base_device<Fq>(ctx, g1, h_s, m - 1, out->h));
+  // bellman refuses a circuit with a variable that no constraint mentions (its l point would be the identity)
+  for (size_t i = 0; i < n_aux; i++)
+    if (icl[n_in + i].is_inf()) return fail(ctx, ZG16_ERR_UNCONSTRAINED_VARIABLE, "aux variable %zu occurs in no constraint", i);
+  memcpy(out->ic, icl.data(), n_in * sizeof(G1Affine));
+  if (n_aux) memcpy(out->l, icl.data() + n_in, n_aux * sizeof(G1Affine));
+  // a, b_g1, b_g2 keep only the variables whose polynomial is non-zero (inputs first, then aux, order kept)
+  size_t na = 0, nb = 0;
+  for (size_t i = 0; i < nv; i++) {
+    if (!pa[i].is_inf()) memcpy(out->a + 8 * na++, &pa[i], sizeof(G1Affine));
+    if (!pb1[i].is_inf()) {
+      memcpy(out->b_g1 + 8 * nb, &pb1[i], sizeof(G1Affine));
+      memcpy(out->b_g2 + 16 * nb, &pb2[i], sizeof(G2Affine));
+      nb++;
+    }
+  }
+  out->n_a = na;
+  out->n_b = nb;
+  // the verifying key's own points
+  Fr* vk_s;
+  ZG_TRY(scratch_get(ctx, 7, 4 * sizeof(Fr), (void**)&vk_s));
+  const Fr vks[4] = {alpha, beta, delta, gamma};
+  ZG_HIP(ctx, hipMemcpyAsync(vk_s, vks, sizeof vks, hipMemcpyHostToDevice, ctx->stream));
+  G1Affine v1[3];
+  G2Affine v2[3];
+  ZG_TRY(fixed_base_device<Fq>(ctx, g1, vk_s, 3, v1));
+  ZG_TRY(fixed_base_device<Fq2>(ctx, g2, vk_s + 1, 3, v2));
+  memcpy(out->alpha_g1, &v1[0], 64); memcpy(out->beta_g1, &v1[1], 64); memcpy(out->delta_g1, &v1[2], 64);
+  memcpy(out->beta_g2, &v2[0], 128); memcpy(out->delta_g2, &v2[1], 128); memcpy(out->gamma_g2, &v2[2], 128);
   return ZG16_OK;
 }
 
@@ -85,5 +266,10 @@ zg16_status zg16_fixed_base_g1(zg16_ctx* ctx, const uint64_t base[8], const uint
 }
 zg16_status zg16_fixed_base_g2(zg16_ctx* ctx, const uint64_t base[16], const uint64_t* scalars, size_t n, uint64_t* out) {
   return zg::fixed_base<zg::Fq2>(ctx, base, scalars, n, out);
+}
+zg16_status zg16_generate_parameters(zg16_ctx* ctx, const zg16_r1cs_view* circuit, const zg16_toxic_waste* toxic,
+                                     zg16_parameters_out* out) {
+  if (!ctx || !circuit || !toxic || !out) return zg::fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "bad arguments to zg16_generate_parameters");
+  return zg::generate_parameters(ctx, circuit, toxic, out);
 }
 }

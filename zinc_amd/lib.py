@@ -21,6 +21,7 @@ STATUS_NAMES = {
     5: "InvalidArgument",
     6: "DeviceError",
     7: "OutOfMemory",
+    8: "UnconstrainedVariable",
 }
 
 u64p = C.POINTER(C.c_uint64)
@@ -52,6 +53,18 @@ class Proof(C.Structure):
 class Partial(C.Structure):
     _fields_ = [("hl", C.c_uint64 * 16), ("a", C.c_uint64 * 16), ("b1", C.c_uint64 * 16),
                 ("b2", C.c_uint64 * 32)]
+
+
+class ToxicWaste(C.Structure):
+    _fields_ = [("g1", C.c_uint64 * 8), ("g2", C.c_uint64 * 16), ("alpha", C.c_uint64 * 4), ("beta", C.c_uint64 * 4),
+                ("gamma", C.c_uint64 * 4), ("delta", C.c_uint64 * 4), ("tau", C.c_uint64 * 4)]
+
+
+class ParametersOut(C.Structure):
+    _fields_ = [("alpha_g1", C.c_uint64 * 8), ("beta_g1", C.c_uint64 * 8), ("beta_g2", C.c_uint64 * 16),
+                ("gamma_g2", C.c_uint64 * 16), ("delta_g1", C.c_uint64 * 8), ("delta_g2", C.c_uint64 * 16),
+                ("ic", u64p), ("h", u64p), ("l", u64p), ("a", u64p), ("n_a", C.c_size_t), ("b_g1", u64p),
+                ("b_g2", u64p), ("n_b", C.c_size_t)]
 
 
 class CacheCounts(C.Structure):
@@ -128,6 +141,8 @@ SYMBOLS = [
     ("zg16_spmv", C.c_int, [C.c_void_p, C.c_void_p, u64p, u64p, u64p, u64p, u64p]),
     ("zg16_fixed_base_g1", C.c_int, [C.c_void_p, u64p, u64p, C.c_size_t, u64p]),
     ("zg16_fixed_base_g2", C.c_int, [C.c_void_p, u64p, u64p, C.c_size_t, u64p]),
+    ("zg16_generate_parameters", C.c_int, [C.c_void_p, C.POINTER(R1csView), C.POINTER(ToxicWaste),
+                                           C.POINTER(ParametersOut)]),
     ("zg16_selftest_field", C.c_int, [C.c_void_p, C.c_int, C.c_int, u64p, u64p, C.c_size_t, u64p]),
     ("zg16_selftest_group", C.c_int, [C.c_void_p, C.c_int, C.c_int, u64p, u64p, C.c_size_t, u64p]),
     ("zg16_profile_enable", C.c_int, [C.c_void_p, C.c_int]),

@@ -129,7 +129,47 @@ def _generators():
 
 
 def generate_parameters(ctx, circuit, toxic):
-    """Groth16 setup for a SyntheticCircuit with explicit toxic waste.
+    """bellman `generate_parameters` on the GPU (zg16_generate_parameters) with explicit toxic waste.
+
+    circuit: an R1CS (rows as for proving, input rows appended) or anything with `.r1cs()`.
+    toxic: dict of canonical ints k1, k2 (g1 = k1*G1, g2 = k2*G2), alpha, beta, gamma, delta, tau.
+    Returns Parameters with `.ic` ((n_inputs, 8) vk.ic points) and `.gamma_g2` attached.
+    """
+    r1cs = circuit if isinstance(circuit, R1CS) else circuit.r1cs()
+    mont = lambda x: ints_to_mont([x % R_MOD], R_MOD)[0]
+    g1gen, g2gen = _generators()
+    tw = _lib.ToxicWaste()
+    tw.g1[:] = [int(x) for x in fixed_base_g1(ctx, g1gen, mont(toxic["k1"]))[0]]
+    tw.g2[:] = [int(x) for x in fixed_base_g2(ctx, g2gen, mont(toxic["k2"]))[0]]
+    for name in ("alpha", "beta", "gamma", "delta", "tau"):
+        getattr(tw, name)[:] = [int(x) for x in mont(toxic[name])]
+    m = 1
+    while m < r1cs.n_rows:
+        m *= 2
+    nv = r1cs.n_inputs + r1cs.n_aux
+    ic = np.zeros((r1cs.n_inputs, 8), dtype=np.uint64)
+    h = np.zeros((max(m - 1, 1), 8), dtype=np.uint64)
+    l = np.zeros((max(r1cs.n_aux, 1), 8), dtype=np.uint64)
+    a = np.zeros((nv, 8), dtype=np.uint64)
+    b1 = np.zeros((nv, 8), dtype=np.uint64)
+    b2 = np.zeros((nv, 16), dtype=np.uint64)
+    out = _lib.ParametersOut()
+    out.ic, out.h, out.l = _lib.as_u64p(ic), _lib.as_u64p(h), _lib.as_u64p(l)
+    out.a, out.b_g1, out.b_g2 = _lib.as_u64p(a), _lib.as_u64p(b1), _lib.as_u64p(b2)
+    view = r1cs.view()
+    _check(ctx.handle, ctx._lib.zg16_generate_parameters(ctx.handle, C.byref(view), C.byref(tw), C.byref(out)))
+    arr = lambda f, w: np.array(list(f), dtype=np.uint64).reshape(1, w)
+    params = Parameters(alpha_g1=arr(out.alpha_g1, 8), beta_g1=arr(out.beta_g1, 8), beta_g2=arr(out.beta_g2, 16),
+                        delta_g1=arr(out.delta_g1, 8), delta_g2=arr(out.delta_g2, 16), h=h[:m - 1], l=l[:r1cs.n_aux],
+                        a=a[:out.n_a].copy(), b_g1=b1[:out.n_b].copy(), b_g2=b2[:out.n_b].copy())
+    params.gamma_g2 = arr(out.gamma_g2, 16)
+    params.ic = ic
+    return params
+
+
+def generate_parameters_host(ctx, circuit, toxic):
+    """The same key with the per-variable sums computed on the host by libzg16_tools (a SyntheticCircuit only):
+    an independent check of zg16_generate_parameters.
 
     toxic: dict of canonical ints k1, k2 (g1 = k1*G1, g2 = k2*G2), alpha, beta, gamma, delta, tau.
     Returns (Parameters, ic) where ic is the (n_inputs, 8) array of vk.ic points.
