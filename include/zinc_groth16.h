@@ -372,6 +372,22 @@ typedef struct {
 zg16_status zg16_generate_parameters(zg16_ctx* ctx, const zg16_r1cs_view* circuit, const zg16_toxic_waste* toxic,
                                      zg16_parameters_out* out);
 
+/* bellman `verify_proof(&prepare_verifying_key(&vk), &proof, &public_inputs)` (zinc-vm/src/core/facade.rs:32-38;
+ * the check zinc-tester ends every proof test with, zinc-tester/src/runners/proof_check.rs:243-264).  Host
+ * arithmetic only (four Miller loops and one final exponentiation, whatever the circuit size); no context needed.
+ * public_inputs: n_inputs Montgomery Fr, without the leading ONE.  ic holds n_ic = n_inputs + 1 points, otherwise
+ * ZG16_ERR_MALFORMED_KEY (bellman's MalformedVerifyingKey).  *accepted = 1 iff
+ * e(A, B) = e(alpha, beta) * e(ic[0] + sum x_i ic[i+1], gamma) * e(C, delta). */
+typedef struct {
+  const uint64_t* alpha_g1; /* 8  */
+  const uint64_t* beta_g2;  /* 16 */
+  const uint64_t* gamma_g2; /* 16 */
+  const uint64_t* delta_g2; /* 16 */
+  const uint64_t* ic;  size_t n_ic;  /* G1 */
+} zg16_vk_view;
+zg16_status zg16_verify_proof(const zg16_vk_view* vk, const zg16_proof* proof, const uint64_t* public_inputs,
+                              size_t n_inputs, int* accepted);
+
 /* ---- timing of the last zg16_prove / zg16_prove_partial on this context -------------------- */
 typedef struct {
   float upload_ms, spmv_ms, ntt_ms, msm_g1_ms, msm_g2_ms, finish_ms, total_ms;

@@ -30,6 +30,8 @@ pub struct zg16_pk_view {
 #[repr(C)]
 pub struct zg16_r1cs_view { pub n_rows: usize, pub n_inputs: usize, pub n_aux: usize, pub a: zg16_csr, pub b: zg16_csr, pub c: zg16_csr }
 #[repr(C)] pub struct zg16_proof { pub a: [u64; 8], pub b: [u64; 16], pub c: [u64; 8] }
+#[repr(C)]
+pub struct zg16_vk_view { pub alpha_g1: *const u64, pub beta_g2: *const u64, pub gamma_g2: *const u64, pub delta_g2: *const u64, pub ic: *const u64, pub n_ic: usize }
 
 extern "C" {
     pub fn zg16_ctx_create(device_id: c_int, out: *mut *mut zg16_ctx) -> c_int;
@@ -57,6 +59,8 @@ extern "C" {
     /// cannot keep a handle (prove.rs:73-88, zinc-tester proof_check.rs:122) pay for the key upload once.
     pub fn zg16_default_ctx(device_id: c_int, out: *mut *mut zg16_ctx) -> c_int;
     pub fn zg16_pk_cached(ctx: *mut zg16_ctx, view: *const zg16_pk_view, full_digest: c_int, out: *mut *mut zg16_pk, was_cached: *mut c_int) -> c_int;
+    /// bellman `verify_proof` (zinc-vm/src/core/facade.rs:32-38); host arithmetic, no context.
+    pub fn zg16_verify_proof(vk: *const zg16_vk_view, proof: *const zg16_proof, public_inputs: *const u64, n_inputs: usize, accepted: *mut c_int) -> c_int;
     pub fn zg16_pk_cache_holds(ctx: *mut zg16_ctx, pk: *const zg16_pk) -> c_int;
     pub fn zg16_r1cs_cached(ctx: *mut zg16_ctx, circuit_id: *const u8, circuit_id_len: usize, view: *const zg16_r1cs_view,
                             out: *mut *mut zg16_r1cs, was_cached: *mut c_int) -> c_int;

@@ -913,3 +913,6 @@ def test_factorial_stand_in_proves_and_verifies(gpu_ctx, n, storage_root):
     public = circ.public_inputs()
     assert G.verify_proof(_vk_of(params), got.as_tuple(), public)
     assert not G.verify_proof(_vk_of(params), got.as_tuple(), [public[0] + 1] + public[1:])
+    # the library's own verifier agrees with the oracle's
+    from zinc_amd.groth16 import verify_proof
+    assert verify_proof(params, got, public) and not verify_proof(params, got, [public[0] + 1] + public[1:])

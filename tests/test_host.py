@@ -288,3 +288,42 @@ def test_factorial_stand_in_rows(n):
     # the matrices do not depend on the input: that is what lets a prover keep them resident per (bytecode, method)
     other = standin.record(standin.FactorialCircuit(3))
     assert other._rp == pa._rp and other._col == pa._col and other._coeff == pa._coeff
+
+
+@pytest.mark.parametrize("idx", [1, 2, 3])
+def test_verify_proof_golden(idx):
+    """zg16_verify_proof (host pairing arithmetic in the library) accepts the fixture proofs the oracle's verifier
+    accepted, and rejects a changed input, a changed proof point and a wrong number of inputs."""
+    from conftest import golden, FixtureKey, fixture_proof
+    from zinc_amd import lib as zlib
+    from zinc_amd.fields import g1_to_mont, g2_to_mont
+    from zinc_amd.groth16 import SynthesisError, verify_proof
+    import time
+    fx = golden("prove_tiny_%d.json" % idx)
+    assert fx["pairing_check"] is True
+    key = FixtureKey(fx)
+
+    class VK:
+        alpha_g1, beta_g2 = g1_to_mont([key.alpha_g1]), g2_to_mont([key.beta_g2])
+        gamma_g2, delta_g2 = g2_to_mont([key.gamma_g2]), g2_to_mont([key.delta_g2])
+        ic = g1_to_mont(key.ic)
+
+    a, b, c = fixture_proof(fx)
+    raw = zlib.Proof()
+    raw.a[:] = [int(x) for x in g1_to_mont([a])[0]]
+    raw.b[:] = [int(x) for x in g2_to_mont([b])[0]]
+    raw.c[:] = [int(x) for x in g1_to_mont([c])[0]]
+    public = [int(x, 16) for x in fx["public_inputs"]]
+    t0 = time.time()
+    assert verify_proof(VK, raw, public)
+    assert time.time() - t0 < 2.0
+    assert not verify_proof(VK, raw, [public[0] + 1] + public[1:])
+    bad = zlib.Proof.from_buffer_copy(bytes(raw))
+    bad.a[:], bad.c[:] = list(raw.c), list(raw.a)     # two valid curve points in the wrong places
+    assert not verify_proof(VK, bad, public)
+    bad = zlib.Proof.from_buffer_copy(bytes(raw))
+    bad.c[0] ^= 1                                      # not on the curve
+    assert not verify_proof(VK, bad, public)
+    with pytest.raises(SynthesisError) as e:
+        verify_proof(VK, raw, public + [1])
+    assert e.value.status_name == "MalformedKey"

@@ -531,6 +531,26 @@ def create_proof(circuit, params, r, s, ctx=None, circuit_id=None):
     return prove_recorded(ctx, key, mat, zi, za, rs[0], rs[1])
 
 
+def verify_proof(params, proof, public_inputs):
+    """bellman `verify_proof(&prepare_verifying_key(&vk), &proof, &public_inputs)` (zinc-vm/src/core/facade.rs:32-38)
+    through zg16_verify_proof.  params: anything with alpha_g1, beta_g2, gamma_g2, delta_g2 and ic as Montgomery limb
+    arrays (a Parameters from workload.generate_parameters has them); proof: a Proof or a lib.Proof;
+    public_inputs: canonical integers, without the leading ONE."""
+    f = lambda x, w: np.ascontiguousarray(x, dtype=np.uint64).reshape(-1, w)
+    alpha, beta, gamma, delta = f(params.alpha_g1, 8), f(params.beta_g2, 16), f(params.gamma_g2, 16), f(params.delta_g2, 16)
+    ic = f(params.ic, 8)
+    vk = _lib.VkView(_lib.as_u64p(alpha), _lib.as_u64p(beta), _lib.as_u64p(gamma), _lib.as_u64p(delta), _lib.as_u64p(ic),
+                     ic.shape[0])
+    raw = proof.raw if isinstance(proof, Proof) else proof
+    xs = ints_to_mont([int(x) % R_MOD for x in public_inputs], R_MOD) if len(public_inputs) else np.zeros((0, 4), dtype=np.uint64)
+    ok = C.c_int()
+    st = _lib.load().zg16_verify_proof(C.byref(vk), C.byref(raw), _lib.as_u64p(xs) if xs.size else None, xs.shape[0],
+                                       C.byref(ok))
+    if st != _lib.OK:
+        raise SynthesisError(st, "zg16_verify_proof")
+    return bool(ok.value)
+
+
 def random_fr(rng=None):
     """ff_ce's `Fr::rand`: 4 x u64, clear the top two bits, retry until below r.  The pattern
     drawn is the Montgomery representation (returned as the canonical value it stands for)."""

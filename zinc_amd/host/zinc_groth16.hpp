@@ -267,6 +267,19 @@ inline Proof create_proof(Circuit& circuit, const Parameters& params, const Limb
   return prover.prove(pa, r, s);
 }
 
+// bellman `verify_proof(&prepare_verifying_key(&vk), &proof, &public_inputs)` (zinc-vm/src/core/facade.rs:32-38).
+// public_inputs without the leading ONE; throws MalformedVerifyingKey when their count does not fit `ic`.
+inline bool verify_proof(const Parameters& params, const Proof& proof, const std::vector<Limbs>& public_inputs) {
+  zg16_vk_view vk{};
+  vk.alpha_g1 = params.alpha_g1.data(); vk.beta_g2 = params.beta_g2.data();
+  vk.gamma_g2 = params.gamma_g2.data(); vk.delta_g2 = params.delta_g2.data();
+  vk.ic = (const uint64_t*)params.ic.data(); vk.n_ic = params.ic.size();
+  int ok = 0;
+  zg16_status st = zg16_verify_proof(&vk, &proof, (const uint64_t*)public_inputs.data(), public_inputs.size(), &ok);
+  if (st != ZG16_OK) throw SynthesisError(st, "verify_proof");
+  return ok != 0;
+}
+
 // ff_ce `Fr::rand`: 4 x u64 (limb 0 first), clear the top two bits, retry until below r.  The pattern
 // drawn is used as the Montgomery representation.  `next_u64` is the caller's RNG.
 template <class Rng>

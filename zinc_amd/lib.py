@@ -67,6 +67,11 @@ class ParametersOut(C.Structure):
                 ("b_g2", u64p), ("n_b", C.c_size_t)]
 
 
+class VkView(C.Structure):
+    _fields_ = [("alpha_g1", u64p), ("beta_g2", u64p), ("gamma_g2", u64p), ("delta_g2", u64p), ("ic", u64p),
+                ("n_ic", C.c_size_t)]
+
+
 class CacheCounts(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in
                 ("keys", "circuits", "key_hits", "key_misses", "circuit_hits", "circuit_misses", "evictions",
@@ -143,6 +148,7 @@ SYMBOLS = [
     ("zg16_fixed_base_g2", C.c_int, [C.c_void_p, u64p, u64p, C.c_size_t, u64p]),
     ("zg16_generate_parameters", C.c_int, [C.c_void_p, C.POINTER(R1csView), C.POINTER(ToxicWaste),
                                            C.POINTER(ParametersOut)]),
+    ("zg16_verify_proof", C.c_int, [C.POINTER(VkView), C.POINTER(Proof), u64p, C.c_size_t, C.POINTER(C.c_int)]),
     ("zg16_selftest_field", C.c_int, [C.c_void_p, C.c_int, C.c_int, u64p, u64p, C.c_size_t, u64p]),
     ("zg16_selftest_group", C.c_int, [C.c_void_p, C.c_int, C.c_int, u64p, u64p, C.c_size_t, u64p]),
     ("zg16_profile_enable", C.c_int, [C.c_void_p, C.c_int]),
