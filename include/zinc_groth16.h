@@ -122,6 +122,15 @@ void        zg16_pk_free(zg16_pk* pk);
 zg16_status zg16_pk_upload_bytes(zg16_ctx* ctx, const uint8_t* data, size_t len, int checked,
                                  int shard_index, int shard_count, zg16_pk** out);
 zg16_status zg16_pk_vk_view(const zg16_pk* pk, zg16_pk_view* out);
+/* How the key is held.  Every query is stored as a window table, 2^(c w) P for the windows w of a c-bit digit,
+ * so that a multiexp needs no doublings; the widths c are per query role.  Full tables cost W = ceil(255 / c) times
+ * the points (about 70 GB for a 2^24-row key); when they would not fit the budget -- the ZG16_TABLE_BUDGET_MB
+ * environment variable, else four fifths of the GPU memory free at upload -- the upload keeps only every
+ * `step`-th window (1 / step of the memory) and the multiexps use `step` bucket sets per result instead of one:
+ * more bucket work, the same proof.  An upload that does not fit even with one window per query fails with
+ * ZG16_ERR_OUT_OF_MEMORY.  Any pointer may be NULL. */
+zg16_status zg16_pk_table_info(const zg16_pk* pk, unsigned* width_h, unsigned* width_witness, unsigned* width_g2,
+                               unsigned* step, size_t* device_bytes);
 
 /* ---- constraint matrices ------------------------------------------------------------------ */
 /* Upload A, B, C once per circuit; the structure does not depend on the witness.  Also derives the

@@ -114,3 +114,36 @@ def test_resident_key_saves_the_upload(gpu_ctx):
             assert np.array_equal(np.frombuffer(bytes(g), dtype=np.uint64), w)
     assert min(times[1:]) < times[0] / 3, times
     gpu_ctx.cache_clear()
+
+
+@pytest.mark.parametrize("budget_mb,want_step", [(None, (1,)), (100, (2,)), (45, (3, 4)), (1, None)])
+def test_table_memory_budget_falls_back_to_fewer_windows(gpu_ctx, monkeypatch, budget_mb, want_step):
+    """A key whose full window tables do not fit the budget keeps every step-th window and the multiexps use `step`
+    bucket sets per result: the proof is the same.  (2^14 rows with the direct tables of small queries switched
+    off, so that the bucket pipeline is what runs.)"""
+    from zinc_amd import workload
+    from zinc_amd.groth16 import prove_recorded, DeviceKey
+    from oracle import cpu_binding as cb
+    monkeypatch.setenv("ZG16_DIRECT_MAX_LOG", "0")
+    circ = workload.SyntheticCircuit(1 << 14, seed=(1, 4, 1, 4))
+    params = workload.generate_parameters(gpu_ctx, circ, dict(k1=5, k2=7, alpha=11, beta=13, gamma=17, delta=19, tau=37))
+    r1cs = circ.r1cs()
+    zi, za = circ.witness()
+    rs = ints_to_mont([0xAAAA, 0xBBBB], R_MOD)
+    st, want, _ = cb.prove(params, r1cs, zi, za, rs[0], rs[1], threads=8)
+    assert st == 0
+    if budget_mb is not None:
+        monkeypatch.setenv("ZG16_TABLE_BUDGET_MB", str(budget_mb))
+    key, mat = params.upload(gpu_ctx), r1cs.upload(gpu_ctx)
+    info = key.table_info()
+    if want_step is not None:
+        assert info["step"] in want_step, info
+    else:
+        assert info["step"] >= 8, info      # nothing fits 1 MB: as few windows as there are
+    if budget_mb is not None and want_step is not None:
+        assert info["device_bytes"] <= budget_mb << 20
+    got = prove_recorded(gpu_ctx, key, mat, zi, za, rs[0], rs[1])
+    for g, w in zip((got.raw.a, got.raw.b, got.raw.c), want):
+        assert np.array_equal(np.frombuffer(bytes(g), dtype=np.uint64), w)
+    key.free()
+    mat.free()

@@ -59,18 +59,18 @@ constexpr uint32_t AUX_BIT = 0x80000000u;
 // Upload `count` points as window 0 of a table of `windows` windows and fill the other windows.
 template <class F>
 zg16_status upload_query(zg16_ctx* ctx, Affine<F>** dst, const void* src, size_t count, uint32_t table_c,
-                         Affine<F>** direct, size_t* device_bytes = nullptr) {
+                         Affine<F>** direct, size_t* device_bytes = nullptr, uint32_t table_step = 1) {
   *dst = nullptr;
   *direct = nullptr;
   if (!count) return ZG16_OK;
-  const size_t windows = table_c ? msm_table_windows(table_c) : 1;
+  const size_t windows = table_c ? msm_table_windows(table_c, table_step) : 1;
   ZG_HIP(ctx, hipMalloc((void**)dst, windows * count * sizeof(Affine<F>)));
   if (device_bytes) *device_bytes += windows * count * sizeof(Affine<F>);
   ZG_HIP(ctx, hipMemcpy(*dst, src, count * sizeof(Affine<F>), hipMemcpyHostToDevice));
   // small queries also get a direct table of every multiple a digit can ask for (built from the ABI-form points)
   if (table_c) ZG_TRY(msm_build_direct<F>(ctx, *dst, count, direct));
   // fills the other windows (if any) and rewrites every point in the multiexp kernels' packed form
-  ZG_TRY(msm_build_table<F>(ctx, *dst, count, table_c));
+  ZG_TRY(msm_build_table<F>(ctx, *dst, count, table_c, table_step));
   return ZG16_OK;
 }
 
@@ -271,12 +271,18 @@ zg16_status zg::pk_upload_impl(zg16_ctx* ctx, const zg16_pk_view* v, int shard_i
   pk->table_c = msm_table_window(largest, 1);
   pk->table_c_h = msm_table_window(pk->hi_h - pk->lo_h, 0);
   pk->table_c_g2 = msm_table_window(pk->hi_b - pk->lo_b, 2);
+  {
+    const TableQuery tq[5] = {{pk->hi_h - pk->lo_h, pk->table_c_h, 64}, {pk->hi_l - pk->lo_l, pk->table_c, 64},
+                              {pk->hi_a - pk->lo_a, pk->table_c, 64}, {pk->hi_b - pk->lo_b, pk->table_c, 64},
+                              {pk->hi_b - pk->lo_b, pk->table_c_g2, 128}};
+    pk->table_step = msm_table_step(tq, 5);
+  }
   ZG_TRY(upload_query<Fq>(ctx, &pk->h, h_cyclic ? h_gathered.data() : v->h + 8 * pk->lo_h, pk->hi_h - pk->lo_h, pk->table_c_h,
-                          &pk->h_d, &pk->device_bytes));
-  ZG_TRY(upload_query<Fq>(ctx, &pk->l, v->l + 8 * pk->lo_l, pk->hi_l - pk->lo_l, pk->table_c, &pk->l_d, &pk->device_bytes));
-  ZG_TRY(upload_query<Fq>(ctx, &pk->a, v->a + 8 * pk->lo_a, pk->hi_a - pk->lo_a, pk->table_c, &pk->a_d, &pk->device_bytes));
-  ZG_TRY(upload_query<Fq>(ctx, &pk->b1, v->b_g1 + 8 * pk->lo_b, pk->hi_b - pk->lo_b, pk->table_c, &pk->b1_d, &pk->device_bytes));
-  ZG_TRY(upload_query<Fq2>(ctx, &pk->b2, v->b_g2 + 16 * pk->lo_b, pk->hi_b - pk->lo_b, pk->table_c_g2, &pk->b2_d, &pk->device_bytes));
+                          &pk->h_d, &pk->device_bytes, pk->table_step));
+  ZG_TRY(upload_query<Fq>(ctx, &pk->l, v->l + 8 * pk->lo_l, pk->hi_l - pk->lo_l, pk->table_c, &pk->l_d, &pk->device_bytes, pk->table_step));
+  ZG_TRY(upload_query<Fq>(ctx, &pk->a, v->a + 8 * pk->lo_a, pk->hi_a - pk->lo_a, pk->table_c, &pk->a_d, &pk->device_bytes, pk->table_step));
+  ZG_TRY(upload_query<Fq>(ctx, &pk->b1, v->b_g1 + 8 * pk->lo_b, pk->hi_b - pk->lo_b, pk->table_c, &pk->b1_d, &pk->device_bytes, pk->table_step));
+  ZG_TRY(upload_query<Fq2>(ctx, &pk->b2, v->b_g2 + 16 * pk->lo_b, pk->hi_b - pk->lo_b, pk->table_c_g2, &pk->b2_d, &pk->device_bytes, pk->table_step));
   memcpy(&pk->alpha_g1, v->alpha_g1, 64);
   memcpy(&pk->beta_g1, v->beta_g1, 64);
   memcpy(&pk->delta_g1, v->delta_g1, 64);
@@ -307,6 +313,17 @@ void zg::pk_destroy(zg16_pk* pk) {
 }
 
 extern "C" {
+
+zg16_status zg16_pk_table_info(const zg16_pk* pk, unsigned* width_h, unsigned* width_witness, unsigned* width_g2,
+                               unsigned* step, size_t* device_bytes) {
+  if (!pk) return ZG16_ERR_INVALID_ARGUMENT;
+  if (width_h) *width_h = pk->table_c_h;
+  if (width_witness) *width_witness = pk->table_c;
+  if (width_g2) *width_g2 = pk->table_c_g2;
+  if (step) *step = pk->table_step;
+  if (device_bytes) *device_bytes = pk->device_bytes;
+  return ZG16_OK;
+}
 
 // --------------------------------------------------------------------------- constraint matrices
 zg16_status zg16_r1cs_upload(zg16_ctx* ctx, const zg16_r1cs_view* v, zg16_r1cs** out) {
@@ -532,11 +549,11 @@ static zg16_status prove_partial_impl(zg16_ctx* ctx, const zg16_pk* pk, const zg
   const size_t lo_h = pk->lo_h < hi_h ? pk->lo_h : hi_h;
   // the h table is laid out for the whole shard; skip the points below lo_h when the range was clipped
   const MsmJob<Fq> job_h = {pk->h + (lo_h - pk->lo_h), h_coeffs + lo_h, nullptr, hi_h - lo_h, stride(pk->lo_h, pk->hi_h), pk->table_c_h, 0,
-                            pk->h_d ? pk->h_d + (lo_h - pk->lo_h) : nullptr};
+                            pk->h_d ? pk->h_d + (lo_h - pk->lo_h) : nullptr, pk->table_step};
   const MsmJob<Fq> jobs_z[3] = {
-      {pk->l, z + r->n_in + pk->lo_l, nullptr, pk->hi_l - pk->lo_l, stride(pk->lo_l, pk->hi_l), tc, 0, pk->l_d},
-      {pk->a, z, r->a_map + pk->lo_a, pk->hi_a - pk->lo_a, stride(pk->lo_a, pk->hi_a), tc, 1, pk->a_d},
-      {pk->b1, z, r->b_map + pk->lo_b, pk->hi_b - pk->lo_b, stride(pk->lo_b, pk->hi_b), tc, 2, pk->b1_d}};
+      {pk->l, z + r->n_in + pk->lo_l, nullptr, pk->hi_l - pk->lo_l, stride(pk->lo_l, pk->hi_l), tc, 0, pk->l_d, pk->table_step},
+      {pk->a, z, r->a_map + pk->lo_a, pk->hi_a - pk->lo_a, stride(pk->lo_a, pk->hi_a), tc, 1, pk->a_d, pk->table_step},
+      {pk->b1, z, r->b_map + pk->lo_b, pk->hi_b - pk->lo_b, stride(pk->lo_b, pk->hi_b), tc, 2, pk->b1_d, pk->table_step}};
   // The main stream is the critical path (rows -> transforms -> h multiexp) and is enqueued first, so
   // the GPU is not left waiting while the host queues the other pipelines' launches.
   if (!h_external) {
@@ -556,7 +573,7 @@ static zg16_status prove_partial_impl(zg16_ctx* ctx, const zg16_pk* pk, const zg
   {
     ZG_HIP(ctx, hipStreamWaitEvent(aux, ev[E_Z], 0));
     ZG_HIP(ctx, hipEventRecord(ev[E_G2_BEGIN], aux));
-    MsmJob<Fq2> jb = {pk->b2, z, r->b_map + pk->lo_b, pk->hi_b - pk->lo_b, stride(pk->lo_b, pk->hi_b), pk->table_c_g2, 0, pk->b2_d};
+    MsmJob<Fq2> jb = {pk->b2, z, r->b_map + pk->lo_b, pk->hi_b - pk->lo_b, stride(pk->lo_b, pk->hi_b), pk->table_c_g2, 0, pk->b2_d, pk->table_step};
     const MsmStreams ms = {aux, nullptr, nullptr, nullptr};
     ZG_TRY(msm_launch<Fq2>(ctx, ms, 2, pinned + MSM_PINNED_BYTES, &jb, 1, 1, &pend_g2));
     ZG_HIP(ctx, hipEventRecord(ev[E_G2_END], aux));
@@ -990,11 +1007,15 @@ zg16_status zg16_bases_upload(zg16_ctx* ctx, int group, const uint64_t* bases, s
   b->group = group;
   b->n = n;
   b->table_c = window_tables ? msm_table_window(n, 0) : 0;
+  if (b->table_c) {
+    const TableQuery tq = {n, b->table_c, group == 1 ? 64u : 128u};
+    b->table_step = msm_table_step(&tq, 1);
+  }
   // the handle's fields receive the arrays as they are allocated, so zg16_bases_free releases them on any failure
   if (group == 1)
-    ZG_TRY(upload_query<Fq>(ctx, (Affine<Fq>**)&b->points, bases, n, b->table_c, (Affine<Fq>**)&b->direct));
+    ZG_TRY(upload_query<Fq>(ctx, (Affine<Fq>**)&b->points, bases, n, b->table_c, (Affine<Fq>**)&b->direct, nullptr, b->table_step));
   else
-    ZG_TRY(upload_query<Fq2>(ctx, (Affine<Fq2>**)&b->points, bases, n, b->table_c, (Affine<Fq2>**)&b->direct));
+    ZG_TRY(upload_query<Fq2>(ctx, (Affine<Fq2>**)&b->points, bases, n, b->table_c, (Affine<Fq2>**)&b->direct, nullptr, b->table_step));
   *out = b.release();
   return ZG16_OK;
 }
@@ -1020,13 +1041,13 @@ zg16_status zg16_msm_resident(zg16_ctx* ctx, const zg16_bases* b, const uint64_t
   }
   const size_t stride = b->table_c ? b->n : 0;
   if (b->group == 1) {
-    MsmJob<Fq> job = {(const Affine<Fq>*)b->points, d_s, nullptr, b->n, stride, b->table_c, 0, (const Affine<Fq>*)b->direct};
+    MsmJob<Fq> job = {(const Affine<Fq>*)b->points, d_s, nullptr, b->n, stride, b->table_c, 0, (const Affine<Fq>*)b->direct, b->table_step};
     G1XYZZ res;
     ZG_TRY(msm_g1_device(ctx, &job, 1, &res));
     const G1Affine a = to_affine(res);
     memcpy(out, &a, sizeof a);
   } else {
-    MsmJob<Fq2> job = {(const Affine<Fq2>*)b->points, d_s, nullptr, b->n, stride, b->table_c, 0, (const Affine<Fq2>*)b->direct};
+    MsmJob<Fq2> job = {(const Affine<Fq2>*)b->points, d_s, nullptr, b->n, stride, b->table_c, 0, (const Affine<Fq2>*)b->direct, b->table_step};
     G2XYZZ res;
     ZG_TRY(msm_g2_device(ctx, &job, 1, &res));
     const G2Affine a = to_affine(res);

@@ -193,20 +193,32 @@ struct MsmJob {
   const Fr* scalars;
   const uint32_t* index;  // optional gather map into scalars
   size_t n;
-  // Non-zero when `bases` is a window table: bases[w * table_stride + k] = 2^(table_c * w) * P_k.
+  // Non-zero when `bases` is a window table: bases[w * table_stride + k] = 2^(table_c * table_step * w) * P_k.
   size_t table_stride;
   uint32_t table_c;
   int group;  // which of the launch's results this job is summed into
   // Optional direct table of a small query (msm_build_direct), stride table_stride: when every job of a launch
   // brings one, the multiexp is a plain sum of looked-up multiples and `bases` is not read.
   const Affine<F>* direct = nullptr;
+  // A table may hold only every table_step-th window (it then costs 1 / table_step of the memory): digit window w
+  // looks up table window w / table_step and goes to bucket set w mod table_step of its group; the sets are
+  // recombined as sum_j 2^(c j) set_j.  1: every window, one bucket set per group.
+  uint32_t table_step = 1;
 };
 // Window width / count used for key tables, and the kernel that fills windows 1..W-1 of a table whose
 // window 0 (n points, stride n) is already in place.
 uint32_t msm_table_window(size_t points, int role);  // role 0: h, 1: l / a / b_g1, 2: b_g2
-uint32_t msm_table_windows(uint32_t c);
+uint32_t msm_table_windows(uint32_t c, uint32_t step = 1);  // windows a table of width c holds when it keeps every step-th
+// Smallest step for which `bytes_full / step` (about) fits the table memory budget: the ZG16_TABLE_BUDGET_MB
+// environment variable, else four fifths of the GPU memory that is free now.  sizes: (points, width c, bytes per
+// point) of every query that shares the step.  max_sets bounds step * groups so that the buckets stay addressable.
+struct TableQuery {
+  size_t points;
+  uint32_t c, point_bytes;
+};
+uint32_t msm_table_step(const TableQuery* queries, int count);
 template <class F>
-zg16_status msm_build_table(zg16_ctx* ctx, Affine<F>* table, size_t n, uint32_t c);
+zg16_status msm_build_table(zg16_ctx* ctx, Affine<F>* table, size_t n, uint32_t c, uint32_t step = 1);
 // Direct table of a small query: every multiple d * 2^(5 w) * P_k a signed 5-bit digit can ask for, as affine
 // points in the multiexp kernels' packed form: direct[(w * 16 + (d - 1)) * n + k].  `points` are the n bases in the
 // ABI form (call it before msm_build_table rewrites them).  *out stays null when the query is larger than
@@ -223,10 +235,10 @@ zg16_status msm_g2_device(zg16_ctx* ctx, const MsmJob<Fq2>* jobs, int njobs, G2X
 // (MSM_PINNED_BYTES of page-locked host memory) and returns without waiting; once `ms.main` is idle
 // msm_collect turns the block into `ngroups` points.  Jobs of one launch may form several groups
 // (independent sums) only when every job brings a window table of the same width.
-static constexpr size_t MSM_PINNED_BYTES = 512 * 1024;
+static constexpr size_t MSM_PINNED_BYTES = 1024 * 1024;
 struct MsmPending {
   void* pinned = nullptr;
-  uint32_t nsets = 0, ngroups = 0, c = 0, shared = 0;
+  uint32_t nsets = 0, ngroups = 0, c = 0, shared = 0, step = 1;
   uint32_t direct = 0;  // the results are plain sums (one point per group), nothing to fold
   int acc_kernel = 0;  // KernelId whose work units (additions) are known only after the run
 };

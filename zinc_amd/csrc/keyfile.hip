@@ -140,13 +140,14 @@ struct Cursor {
 // fill the other windows.
 template <class F>
 static zg16_status decode_query(zg16_ctx* ctx, const uint8_t* bytes, size_t lo, size_t hi, int checked, uint32_t table_c,
-                                const Fq2& curve_b, const char* name, Affine<F>** dst, Affine<F>** direct) {
+                                uint32_t table_step, const Fq2& curve_b, const char* name, Affine<F>** dst,
+                                Affine<F>** direct) {
   *dst = nullptr;
   *direct = nullptr;
   const size_t count = hi - lo;
   if (!count) return ZG16_OK;
   constexpr size_t PB = sizeof(Affine<F>);  // the encoding is as long as the affine point
-  const size_t windows = table_c ? msm_table_windows(table_c) : 1;
+  const size_t windows = table_c ? msm_table_windows(table_c, table_step) : 1;
   ZG_HIP(ctx, hipMalloc((void**)dst, windows * count * sizeof(Affine<F>)));
   uint8_t* raw;
   ZG_TRY(scratch_get(ctx, 5, count * PB + 256, (void**)&raw));
@@ -165,7 +166,7 @@ static zg16_status decode_query(zg16_ctx* ctx, const uint8_t* bytes, size_t lo, 
   ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (herr) return fail(ctx, ZG16_ERR_MALFORMED_KEY, "%s query: %s", name, decode_text(herr));
   if (table_c) ZG_TRY(msm_build_direct<F>(ctx, *dst, count, direct));
-  return msm_build_table<F>(ctx, *dst, count, table_c);
+  return msm_build_table<F>(ctx, *dst, count, table_c, table_step);
 }
 
 }  // namespace zg
@@ -242,11 +243,17 @@ zg16_status zg16_pk_upload_bytes(zg16_ctx* ctx, const uint8_t* data, size_t len,
   pk->table_c = msm_table_window(largest, 1);
   pk->table_c_h = msm_table_window(pk->hi_h - pk->lo_h, 0);
   pk->table_c_g2 = msm_table_window(pk->hi_b - pk->lo_b, 2);
-  ZG_TRY(decode_query<Fq>(ctx, vec[0], pk->lo_h, pk->hi_h, checked, pk->table_c_h, curve_b, names[0], &pk->h, &pk->h_d));
-  ZG_TRY(decode_query<Fq>(ctx, vec[1], pk->lo_l, pk->hi_l, checked, pk->table_c, curve_b, names[1], &pk->l, &pk->l_d));
-  ZG_TRY(decode_query<Fq>(ctx, vec[2], pk->lo_a, pk->hi_a, checked, pk->table_c, curve_b, names[2], &pk->a, &pk->a_d));
-  ZG_TRY(decode_query<Fq>(ctx, vec[3], pk->lo_b, pk->hi_b, checked, pk->table_c, curve_b, names[3], &pk->b1, &pk->b1_d));
-  ZG_TRY(decode_query<Fq2>(ctx, vec[4], pk->lo_b, pk->hi_b, checked, pk->table_c_g2, curve_b, names[4], &pk->b2, &pk->b2_d));
+  {
+    const TableQuery tq[5] = {{pk->hi_h - pk->lo_h, pk->table_c_h, 64}, {pk->hi_l - pk->lo_l, pk->table_c, 64},
+                              {pk->hi_a - pk->lo_a, pk->table_c, 64}, {pk->hi_b - pk->lo_b, pk->table_c, 64},
+                              {pk->hi_b - pk->lo_b, pk->table_c_g2, 128}};
+    pk->table_step = msm_table_step(tq, 5);
+  }
+  ZG_TRY(decode_query<Fq>(ctx, vec[0], pk->lo_h, pk->hi_h, checked, pk->table_c_h, pk->table_step, curve_b, names[0], &pk->h, &pk->h_d));
+  ZG_TRY(decode_query<Fq>(ctx, vec[1], pk->lo_l, pk->hi_l, checked, pk->table_c, pk->table_step, curve_b, names[1], &pk->l, &pk->l_d));
+  ZG_TRY(decode_query<Fq>(ctx, vec[2], pk->lo_a, pk->hi_a, checked, pk->table_c, pk->table_step, curve_b, names[2], &pk->a, &pk->a_d));
+  ZG_TRY(decode_query<Fq>(ctx, vec[3], pk->lo_b, pk->hi_b, checked, pk->table_c, pk->table_step, curve_b, names[3], &pk->b1, &pk->b1_d));
+  ZG_TRY(decode_query<Fq2>(ctx, vec[4], pk->lo_b, pk->hi_b, checked, pk->table_c_g2, pk->table_step, curve_b, names[4], &pk->b2, &pk->b2_d));
   *out = pk.release();
   return ZG16_OK;
 }

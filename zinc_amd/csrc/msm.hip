@@ -59,6 +59,7 @@ struct JobTable {
   uint32_t start[MAX_JOBS + 1];  // prefix offsets of the concatenated term list
   uint32_t group[MAX_JOBS];      // which result (bucket set) the job's terms are summed into
   const Affine<F>* direct[MAX_JOBS];  // direct tables (k_direct_sum), stride `stride`
+  uint32_t windows;                   // windows a table holds (1 when the buckets are per-window)
   int njobs;
 };
 
@@ -68,8 +69,9 @@ struct MsmShape {
   uint32_t W;        // windows
   uint32_t B;        // buckets per bucket set = 2^(c-1)
   uint32_t nb;       // digit buckets (G*B shared, W*B per-window); bucket nb + g collects group g's unit scalars
-  uint32_t shared;   // 1: all windows share one bucket set per group (table lookup), 0: one set per window
+  uint32_t shared;   // 1: the windows of a group share `f` bucket sets (table lookup), 0: one set per window
   uint32_t G;        // groups = independent results (1 unless shared)
+  uint32_t f;        // shared only: the tables keep every f-th window; window w uses table window w / f and set w mod f
 };
 
 template <class F>
@@ -88,11 +90,25 @@ ZG_D Fr load_scalar(const JobTable<F>& jt, uint32_t i, int j) {
   return jt.scalars[j][si];
 }
 
-// address of the base of term i for window w (w = 0 when the buckets are per-window)
+// address of the base of term i for window w (w = 0 when the buckets are per-window).  The job's fields are picked
+// by a chain of selects over constant indices: indexing the argument arrays with a per-lane job number makes the
+// compiler read them back from memory, one more dependent load in front of every base.
 template <class F>
 ZG_D const Affine<F>* base_ptr(const JobTable<F>& jt, uint32_t i, uint32_t w) {
-  const int j = find_job(jt, i);
-  return jt.bases[j] + ((size_t)w * jt.stride[j] + (i - jt.start[j]));
+  const Affine<F>* b = jt.bases[0];
+  uint32_t stride = jt.stride[0], start = jt.start[0], end = jt.start[1];
+#pragma unroll
+  for (int k = 1; k < MAX_JOBS; k++) {
+    const bool in = k < jt.njobs && i >= jt.start[k];
+    b = in ? jt.bases[k] : b;
+    stride = in ? jt.stride[k] : stride;
+    start = in ? jt.start[k] : start;
+    end = in ? jt.start[k + 1] : end;
+  }
+  // (an index beyond the term list or the table can only come from a damaged sort entry; it is clamped so that such
+  // a bug reads a wrong base instead of faulting the GPU)
+  const uint32_t local = i - start, last = end - 1 - start;
+  return b + ((size_t)(w < jt.windows ? w : 0) * stride + (local < last ? local : last));
 }
 
 // bits [lo, lo+c) of a 256-bit little-endian integer (c <= 24)
@@ -142,7 +158,7 @@ ZG_D void term_digits(const JobTable<F>& jt, const MsmShape& sh, uint32_t i, FD 
     if (s.v[0]) one(jt.group[j]);
     return;
   }
-  const uint32_t set_base = sh.shared ? jt.group[j] * sh.B : 0;
+  const uint32_t set_base = sh.shared ? jt.group[j] * sh.f * sh.B : 0;
   uint32_t carry = 0;
   for (uint32_t w = 0; w < sh.W; w++) {
     uint32_t d = extract_bits(s.v, w * sh.c, sh.c) + carry;
@@ -153,7 +169,12 @@ ZG_D void term_digits(const JobTable<F>& jt, const MsmShape& sh, uint32_t i, FD 
       neg = 1;
       carry = 1;
     }
-    if (d) digit(sh.shared ? set_base + d - 1 : w * sh.B + d - 1, w, neg);
+    if (d) {
+      if (sh.shared)
+        digit(set_base + (w % sh.f) * sh.B + d - 1, w / sh.f, neg);
+      else
+        digit(w * sh.B + d - 1, w, neg);
+    }
   }
 }
 
@@ -401,6 +422,11 @@ ZG_D uint32_t piece_slot(uint32_t s, uint32_t K, uint32_t piece) {
 // the bucket sizes are (K = chunk_len of the entry count off[nb], read on the device).  A run that
 // lies inside the chunk finishes its bucket; a run cut by a chunk edge leaves a partial sum in slot
 // 2t (first run) or 2t+1 (last run) for k_combine / k_heavy.
+//
+// (Measured and dropped: fetching the base of entry i + 1 by direct-to-LDS loads while entry i is added, sort
+// entries in an LDS ring two ahead, no load left inside the loop.  Bit-identical, and 3 % SLOWER at 2^20 rows: with
+// four waves per SIMD the gather latency is already hidden -- the fifth of the issue slots this kernel leaves empty
+// is the 64-bit multiply-add's own issue rate, two thirds of the 32-bit rate, not a wait for memory.)
 template <class F>
 __global__ __launch_bounds__(256, kMinWaves<F>) void k_accumulate(JobTable<F> jt, uint32_t nb, uint32_t lanes,
                                                                   const uint2* __restrict__ rec,
@@ -748,7 +774,8 @@ __global__ __launch_bounds__(256, kMinWaves<F>) void k_direct_sum(JobTable<F> jt
 }
 
 // table[w*stride + i] = 2^(c*w) * table[i] for w in 1..W-1, every window in the internal packed form
-// (window 0 arrives in the ABI form and is rewritten).  W = 1 just converts the points.
+// (window 0 arrives in the ABI form and is rewritten).  W = 1 just converts the points.  (c here is the distance
+// between two stored windows in bits: the digit width times the table step.)
 template <class F>
 __global__ __launch_bounds__(256, 1) void k_build_table(Affine<F>* __restrict__ table, uint32_t n, uint32_t stride,
                                                         uint32_t W, uint32_t c) {
@@ -801,19 +828,49 @@ uint32_t msm_table_window(size_t points, int role) {
   return (uint32_t)c;
 }
 
-uint32_t msm_table_windows(uint32_t c) { return (255 + c - 1) / c; }
+uint32_t msm_table_windows(uint32_t c, uint32_t step) {
+  const uint32_t W = (255 + c - 1) / c;
+  return (W + step - 1) / step;
+}
+
+uint32_t msm_table_step(const TableQuery* q, int count) {
+  size_t budget;
+  const char* e = getenv("ZG16_TABLE_BUDGET_MB");
+  if (e) {
+    budget = (size_t)atol(e) << 20;
+  } else {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 1;
+    budget = free_b / 5 * 4;
+  }
+  uint32_t max_w = 1, max_b = 1;
+  for (int i = 0; i < count; i++) {
+    if (!q[i].c || !q[i].points) continue;
+    max_w = std::max(max_w, msm_table_windows(q[i].c));
+    max_b = std::max(max_b, 1u << (q[i].c - 1));
+  }
+  // MAX_JOBS groups of `step` bucket sets each must stay below the 24-bit bucket index of a sort entry
+  const uint32_t max_step = std::max(1u, std::min(max_w, (KEY_MASK - 16) / ((uint32_t)MAX_JOBS * max_b)));
+  for (uint32_t step = 1; step <= max_step; step++) {
+    size_t bytes = 0;
+    for (int i = 0; i < count; i++)
+      if (q[i].c) bytes += q[i].points * msm_table_windows(q[i].c, step) * q[i].point_bytes;
+    if (bytes <= budget) return step;
+  }
+  return max_step;  // the fewest windows there are; an allocation that still does not fit reports out of memory
+}
 
 template <class F>
-zg16_status msm_build_table(zg16_ctx* ctx, Affine<F>* table, size_t n, uint32_t c) {
+zg16_status msm_build_table(zg16_ctx* ctx, Affine<F>* table, size_t n, uint32_t c, uint32_t step) {
   if (!n) return ZG16_OK;
   k_build_table<F><<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(table, (uint32_t)n, (uint32_t)n,
-                                                                        c ? msm_table_windows(c) : 1, c);
+                                                                        c ? msm_table_windows(c, step) : 1, c * step);
   ZG_HIP(ctx, hipGetLastError());
   ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return ZG16_OK;
 }
-template zg16_status msm_build_table<Fq>(zg16_ctx*, Affine<Fq>*, size_t, uint32_t);
-template zg16_status msm_build_table<Fq2>(zg16_ctx*, Affine<Fq2>*, size_t, uint32_t);
+template zg16_status msm_build_table<Fq>(zg16_ctx*, Affine<Fq>*, size_t, uint32_t, uint32_t);
+template zg16_status msm_build_table<Fq2>(zg16_ctx*, Affine<Fq2>*, size_t, uint32_t, uint32_t);
 
 // How a set of 2^bits buckets is folded on the device: R*H buckets -> U (R) and V (H), then
 // U -> r1 + h1 points and V -> r2 + h2 points, all sizes powers of two (logarithms held here).
@@ -845,7 +902,7 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
   size_t n = 0;
   int nj = 0;
   bool all_tables = true, all_direct = true;  // direct: every job has a direct table and is its own group
-  uint32_t table_c = 0;
+  uint32_t table_c = 0, table_step = 0;
   for (int j = 0; j < njobs; j++) {
     if (!jobs[j].n) continue;
     if (jobs[j].group < 0 || jobs[j].group >= ngroups) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "bad multiexp group");
@@ -857,12 +914,14 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
     jt.group[nj] = (uint32_t)jobs[j].group;
     jt.direct[nj] = jobs[j].direct;
     if (!jobs[j].direct || jobs[j].group != nj) all_direct = false;
-    if (!jobs[j].table_stride || (table_c && jobs[j].table_c != table_c)) all_tables = false;
+    if (!jobs[j].table_stride || (table_c && (jobs[j].table_c != table_c || jobs[j].table_step != table_step))) all_tables = false;
     table_c = jobs[j].table_c;
+    table_step = jobs[j].table_step;
     n += jobs[j].n;
     nj++;
   }
   jt.njobs = nj;
+  jt.windows = 1;
   for (int j = nj; j <= MAX_JOBS; j++) jt.start[j] = (uint32_t)n;
   pend->pinned = pinned;
   pend->ngroups = (uint32_t)ngroups;
@@ -922,10 +981,12 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
   sh.c = sh.shared ? table_c : pick_window(n);
   sh.W = (255 + sh.c - 1) / sh.c;
   sh.B = 1u << (sh.c - 1);
-  sh.nb = sh.shared ? sh.G * sh.B : sh.W * sh.B;
+  sh.f = sh.shared ? std::max(1u, std::min(table_step, sh.W)) : 1;
+  sh.nb = sh.shared ? sh.G * sh.f * sh.B : sh.W * sh.B;
+  jt.windows = sh.shared ? msm_table_windows(sh.c, sh.f) : 1;
   if (!sh.shared)
     for (int j = 0; j < nj; j++) jt.stride[j] = 0;
-  const uint32_t nsets = sh.shared ? sh.G : sh.W;
+  const uint32_t nsets = sh.shared ? sh.G * sh.f : sh.W;
   const size_t max_entries = (size_t)sh.W * n;
   if (max_entries >= 0xfffffff0ull) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "multiexp too large for 32-bit entry offsets");
   if (sh.nb + sh.G > KEY_MASK) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "too many multiexp buckets");
@@ -1080,6 +1141,7 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
   pend->acc_kernel = is_g2 ? K_MSM_ACC0_G2 : K_MSM_ACC0_G1;
   pend->c = sh.c;
   pend->shared = sh.shared;
+  pend->step = sh.f;
   return ZG16_OK;
 }
 
@@ -1135,9 +1197,17 @@ zg16_status msm_collect(zg16_ctx* ctx, const MsmPending* pend, XYZZ<F>* out) {
   const FoldShape fold(pend->c - 1);
   const XYZZ<F>* ones = hw + (size_t)pend->nsets * fold.leaves();
   if (pend->shared) {
+    const uint32_t f = pend->step;
     for (uint32_t g = 0; g < pend->ngroups; g++) {
-      out[g] = fold_finish(hw + (size_t)g * fold.leaves(), fold);
-      add_full(out[g], ones[g]);  // the scalars equal to one
+      // bucket set j of the group collects the windows w = j mod f: sum_j 2^(c j) set_j, by Horner
+      XYZZ<F> acc = XYZZ<F>::inf();
+      for (uint32_t j = f; j-- > 0;) {
+        if (!acc.is_inf())
+          for (uint32_t k = 0; k < pend->c; k++) acc = dbl(acc);
+        add_full(acc, fold_finish(hw + ((size_t)g * f + j) * fold.leaves(), fold));
+      }
+      add_full(acc, ones[g]);  // the scalars equal to one
+      out[g] = acc;
     }
     return ZG16_OK;
   }
@@ -1226,7 +1296,7 @@ extern "C" zg16_status zg16_msm_resident_noalloc(zg16_ctx* ctx, const zg16_bases
   const MsmStreams ms = {ctx->stream, nullptr, nullptr, nullptr};
   MsmPending pend;
   if (b->group == 1) {
-    const MsmJob<Fq> job = {(const Affine<Fq>*)b->points, d_s, nullptr, b->n, b->n, b->table_c, 0, (const Affine<Fq>*)b->direct};
+    const MsmJob<Fq> job = {(const Affine<Fq>*)b->points, d_s, nullptr, b->n, b->n, b->table_c, 0, (const Affine<Fq>*)b->direct, b->table_step};
     ZG_TRY(msm_launch<Fq>(ctx, ms, 1, ctx->pinned, &job, 1, 1, &pend, &fixed));
     ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     G1XYZZ res;
@@ -1234,7 +1304,7 @@ extern "C" zg16_status zg16_msm_resident_noalloc(zg16_ctx* ctx, const zg16_bases
     const G1Affine a = to_affine(res);
     memcpy(out, &a, sizeof a);
   } else {
-    const MsmJob<Fq2> job = {(const Affine<Fq2>*)b->points, d_s, nullptr, b->n, b->n, b->table_c, 0, (const Affine<Fq2>*)b->direct};
+    const MsmJob<Fq2> job = {(const Affine<Fq2>*)b->points, d_s, nullptr, b->n, b->n, b->table_c, 0, (const Affine<Fq2>*)b->direct, b->table_step};
     ZG_TRY(msm_launch<Fq2>(ctx, ms, 2, ctx->pinned, &job, 1, 1, &pend, &fixed));
     ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     G2XYZZ res;

@@ -69,6 +69,9 @@ struct zg16_pk {
   uint32_t table_c = 0;       // l, a, b_g1 (one launch, one width)
   uint32_t table_c_h = 0;     // h
   uint32_t table_c_g2 = 0;    // b_g2
+  // Every table keeps one window in table_step (chosen at upload so that the tables fit the memory budget:
+  // msm_table_step); the multiexps then use table_step bucket sets per result.
+  uint32_t table_step = 1;
   zg::G1Affine alpha_g1, beta_g1, delta_g1;
   zg::G2Affine beta_g2, delta_g2;
   // r * delta_g1 and s * delta_g2 open every proof's assembly on the host; delta is fixed per key, so the key
@@ -102,6 +105,7 @@ struct zg16_bases {
   int group = 1;  // 1 = G1, 2 = G2
   size_t n = 0;
   uint32_t table_c = 0;
+  uint32_t table_step = 1;
   void* points = nullptr;  // Affine<Fq> or Affine<Fq2>, in the multiexp kernels' packed form
   void* direct = nullptr;  // direct table (msm_build_direct) when the set is small and has window tables
 };

@@ -117,7 +117,7 @@ zg16_status zg16_hshard_stage(zg16_hshard* hs, int stage, const uint64_t* z_in, 
     const uint32_t tc = pk->table_c;
     {
       ZG_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, hs->ev_z, 0));
-      MsmJob<Fq2> jb = {pk->b2, z, r->b_map + pk->lo_b, pk->hi_b - pk->lo_b, pk->hi_b - pk->lo_b, pk->table_c_g2, 0, pk->b2_d};
+      MsmJob<Fq2> jb = {pk->b2, z, r->b_map + pk->lo_b, pk->hi_b - pk->lo_b, pk->hi_b - pk->lo_b, pk->table_c_g2, 0, pk->b2_d, pk->table_step};
       const MsmStreams ms = {ctx->aux_stream, nullptr, nullptr, nullptr};
       ZG_TRY(msm_launch<Fq2>(ctx, ms, 2, pinned + MSM_PINNED_BYTES, &jb, 1, 1, &hs->pend_g2));
       ZG_HIP(ctx, hipEventRecord(hs->ev_g2, ctx->aux_stream));
@@ -125,9 +125,9 @@ zg16_status zg16_hshard_stage(zg16_hshard* hs, int stage, const uint64_t* z_in, 
     {
       ZG_HIP(ctx, hipStreamWaitEvent(ctx->early_stream, hs->ev_z, 0));
       const MsmJob<Fq> jobs_z[3] = {
-          {pk->l, z + r->n_in + pk->lo_l, nullptr, pk->hi_l - pk->lo_l, pk->hi_l - pk->lo_l, tc, 0, pk->l_d},
-          {pk->a, z, r->a_map + pk->lo_a, pk->hi_a - pk->lo_a, pk->hi_a - pk->lo_a, tc, 1, pk->a_d},
-          {pk->b1, z, r->b_map + pk->lo_b, pk->hi_b - pk->lo_b, pk->hi_b - pk->lo_b, tc, 2, pk->b1_d}};
+          {pk->l, z + r->n_in + pk->lo_l, nullptr, pk->hi_l - pk->lo_l, pk->hi_l - pk->lo_l, tc, 0, pk->l_d, pk->table_step},
+          {pk->a, z, r->a_map + pk->lo_a, pk->hi_a - pk->lo_a, pk->hi_a - pk->lo_a, tc, 1, pk->a_d, pk->table_step},
+          {pk->b1, z, r->b_map + pk->lo_b, pk->hi_b - pk->lo_b, pk->hi_b - pk->lo_b, tc, 2, pk->b1_d, pk->table_step}};
       const MsmStreams ms = {ctx->early_stream, nullptr, nullptr, nullptr};
       ZG_TRY(msm_launch<Fq>(ctx, ms, 6, pinned + 2 * MSM_PINNED_BYTES, jobs_z, 3, 3, &hs->pend_z));
       ZG_HIP(ctx, hipEventRecord(hs->ev_early, ctx->early_stream));
@@ -152,7 +152,7 @@ zg16_status zg16_hshard_stage(zg16_hshard* hs, int stage, const uint64_t* z_in, 
     const size_t G = (size_t)1 << hs->log_g;
     size_t n_local = m - 1 > hs->shard ? (m - 1 - hs->shard + G - 1) / G : 0;
     if (n_local > pk->hi_h) n_local = pk->hi_h;
-    const MsmJob<Fq> job_h = {pk->h, hs->h, nullptr, n_local, pk->hi_h - pk->lo_h, pk->table_c_h, 0, pk->h_d};
+    const MsmJob<Fq> job_h = {pk->h, hs->h, nullptr, n_local, pk->hi_h - pk->lo_h, pk->table_c_h, 0, pk->h_d, pk->table_step};
     const MsmStreams ms = {st, nullptr, nullptr, nullptr};
     ZG_TRY(msm_launch<Fq>(ctx, ms, 1, ctx->pinned, &job_h, 1, 1, &hs->pend_h));
   }

@@ -264,6 +264,13 @@ class DeviceKey:
                                                          shard_count, C.byref(key.handle)))
         return key
 
+    def table_info(self):
+        """zg16_pk_table_info: dict of the digit widths per query role, the table step and the HBM bytes held."""
+        ch, cw, cg, st, nb = C.c_uint(), C.c_uint(), C.c_uint(), C.c_uint(), C.c_size_t()
+        _check(self.ctx.handle, self.ctx._lib.zg16_pk_table_info(self.handle, C.byref(ch), C.byref(cw), C.byref(cg),
+                                                                 C.byref(st), C.byref(nb)))
+        return dict(width_h=ch.value, width_witness=cw.value, width_g2=cg.value, step=st.value, device_bytes=nb.value)
+
     def vk_view(self):
         v = _lib.PkView()
         _check(self.ctx.handle, self.ctx._lib.zg16_pk_vk_view(self.handle, C.byref(v)))

@@ -93,6 +93,8 @@ SYMBOLS = [
     ("zg16_pk_free", None, [C.c_void_p]),
     ("zg16_pk_upload_bytes", C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
                                        C.POINTER(C.c_void_p)]),
+    ("zg16_pk_table_info", C.c_int, [C.c_void_p, C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint),
+                                     C.POINTER(C.c_uint), C.POINTER(C.c_size_t)]),
     ("zg16_pk_vk_view", C.c_int, [C.c_void_p, C.POINTER(PkView)]),
     ("zg16_default_ctx", C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     ("zg16_shutdown", None, []),
