@@ -143,11 +143,14 @@ class ProveCase:
         self.ctx, self.d, self.log_rows, self.dense, self.split = ctx, d, log_rows, dense, split
         t0 = time.time()
         self.circ = workload.SyntheticCircuit(1 << log_rows, dense=dense)
-        self.params = workload.generate_parameters(ctx, self.circ, TOXIC)
         self.r1cs = self.circ.r1cs()
+        t1 = time.time()
+        self.params = workload.generate_parameters(ctx, self.r1cs, TOXIC)   # zg16_generate_parameters: on the GPU
+        self.keygen_s = time.time() - t1
         self.generate_s = time.time() - t0
         t0 = time.time()
         self.mat = self.r1cs.upload(ctx)
+        self.matrices_upload_s = time.time() - t0
         self.sharded = None
         if split == "sharded":
             from zinc_amd.distributed import ShardedProver
@@ -226,7 +229,8 @@ def secondary_block(ctx, d, args, split_for):
                                 % (log_rows, "dense" if dense else "80% bit"),
                     "ms_per_proof": 1e3 * sec, "constraints_per_s": n_rows / sec, "proofs_timed": reps,
                     "stage_ms_last_proof": stage, "roofline": accumulate_roofline(stats),
-                    "generate_s_untimed": case.generate_s, "key_upload_and_tables_s": case.upload_s,
+                    "generate_s_untimed": case.generate_s, "keygen_on_gpu_s": case.keygen_s, "key_upload_and_tables_s": case.upload_s - case.matrices_upload_s,
+                    "matrices_upload_s": case.matrices_upload_s,
                     "split_transforms": case.split or False}
         finally:
             case.free()
@@ -316,7 +320,39 @@ def secondary_block(ctx, d, args, split_for):
                 "seconds": sec, "points_per_s": n / sec, "bases_s_untimed": t1 - t0, "upload_and_tables_s_untimed": t2 - t1,
                 "roofline": accumulate_roofline(stats)}
 
+    def small_circuit():
+        """The small-circuit latency floor: the hand-recorded factorial.zn stand-in (zinc_amd/standin.py; about
+        1.8 k rows, domain 2^11 -- the size of a real zinc-tester program or contract method), key generated on the
+        GPU, proof checked by the library's verifier against the output the reference's test pins."""
+        from zinc_amd import standin
+        from zinc_amd.groth16 import prove_recorded, verify_proof
+        from zinc_amd.fields import ints_to_mont, R_MOD
+        circ = standin.FactorialCircuit(6)
+        pa = standin.record(circ)
+        r1cs = pa.r1cs()
+        t0 = time.perf_counter()
+        params = workload.generate_parameters(ctx, r1cs, TOXIC)
+        keygen_s = time.perf_counter() - t0
+        key, mat = params.upload(ctx), r1cs.upload(ctx)
+        zi, za = pa.witness()
+        rs = ints_to_mont([pow(7, 123456789, R_MOD), pow(5, 987654321, R_MOD)], R_MOD)
+        try:
+            proof = prove_recorded(ctx, key, mat, zi, za, rs[0], rs[1])
+            sec = d.timed(lambda: prove_recorded(ctx, key, mat, zi, za, rs[0], rs[1]), 50, warmup=3)
+            t0 = time.perf_counter()
+            ok = verify_proof(params, proof, circ.public_inputs())
+            verify_s = time.perf_counter() - t0
+        finally:
+            key.free()
+            mat.free()
+        return {"workload": "hand-recorded stand-in for zinc-tester/tests/algorithm/factorial.zn (n = 6 -> 720), %d rows, "
+                            "witness from host memory" % r1cs.n_rows,
+                "ms_per_proof": 1e3 * sec, "proofs_timed": 50, "verifies_against_pinned_output": bool(ok),
+                "verify_ms_host": 1e3 * verify_s, "keygen_s": keygen_s}
+
     guarded("prove_2p%d" % args.secondary_log_rows, lambda: prove_case(args.secondary_log_rows, False, 3))
+    if d.world == 1:
+        guarded("small_circuit_factorial", small_circuit)
     guarded("prove_2p%d_dense" % min(args.log_rows, 20), lambda: prove_case(min(args.log_rows, 20), True, 10))
     guarded("msm_g1_2p%d" % args.secondary_log_n, msm_standalone)
     guarded("fr_ntt_2p%d" % args.secondary_log_n, ntt_standalone)

@@ -8,8 +8,8 @@
 // and the h and l queries share one multiexp (both only enter C).
 #include <string.h>
 
+#include <atomic>
 #include <chrono>
-
 #include <memory>
 
 #include "r1cs.cuh"
@@ -354,20 +354,26 @@ zg16_status zg16_r1cs_upload(zg16_ctx* ctx, const zg16_r1cs_view* v, zg16_r1cs**
       rp[i] = (uint32_t)m.row_ptr[i];
       if (i && rp[i] - rp[i - 1] > SPMV_LONG_ROW) longs.push_back((uint32_t)(i - 1));
     }
-    for (size_t e = 0; e < nnz; e++) {
-      const uint32_t c = m.col[e];
-      if (c & AUX_BIT) {
-        const uint32_t i = c & ~AUX_BIT;
-        if (i >= v->n_aux) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "matrix %d names aux variable %u of %zu", k, i, v->n_aux);
-        flat[e] = (uint32_t)v->n_inputs + i;
-        if (k == 0) dens_a[i] = 1;
-        if (k == 1) dens_b_aux[i] = 1;
-      } else {
-        if (c >= v->n_inputs) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "matrix %d names input %u of %zu", k, c, v->n_inputs);
-        flat[e] = c;
-        if (k == 1) dens_b_in[c] = 1;
+    // columns -> flat witness indices and the density marks, the entries split over host threads (marks are
+    // single bytes that only ever become one, stored with relaxed atomics)
+    std::atomic<int> bad_col(0);
+    host_parallel(nnz, [&](size_t lo, size_t hi) {
+      for (size_t e = lo; e < hi; e++) {
+        const uint32_t c = m.col[e];
+        if (c & AUX_BIT) {
+          const uint32_t i = c & ~AUX_BIT;
+          if (i >= v->n_aux) { bad_col.store(1); return; }
+          flat[e] = (uint32_t)v->n_inputs + i;
+          if (k == 0) __atomic_store_n(&dens_a[i], (uint8_t)1, __ATOMIC_RELAXED);
+          if (k == 1) __atomic_store_n(&dens_b_aux[i], (uint8_t)1, __ATOMIC_RELAXED);
+        } else {
+          if (c >= v->n_inputs) { bad_col.store(1); return; }
+          flat[e] = c;
+          if (k == 1) __atomic_store_n(&dens_b_in[c], (uint8_t)1, __ATOMIC_RELAXED);
+        }
       }
-    }
+    });
+    if (bad_col.load()) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "matrix %d names a variable the circuit does not have", k);
     R1csMatrix& d = r->m[k];
     d.nnz = nnz;
     d.n_long = (uint32_t)longs.size();

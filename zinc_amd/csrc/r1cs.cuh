@@ -2,6 +2,7 @@
 // handles declared in include/zinc_groth16.h).
 #pragma once
 #include <memory>
+#include <thread>
 
 #include "common.cuh"
 
@@ -24,6 +25,20 @@ struct R1csMatrix {
   uint32_t n_long = 0;
   size_t nnz = 0;
 };
+
+// fn(lo, hi) over [0, n) in contiguous pieces on up to 16 host threads (one piece, inline, when n is small).
+template <class Fn>
+inline void host_parallel(size_t n, Fn fn) {
+  unsigned t = std::thread::hardware_concurrency();
+  t = t < 1 ? 1 : (t > 16 ? 16 : t);
+  if (n < ((size_t)1 << 16) || t == 1) {
+    fn((size_t)0, n);
+    return;
+  }
+  std::vector<std::thread> pool;
+  for (unsigned i = 0; i < t; i++) pool.emplace_back([=] { fn(n * i / t, n * (i + 1) / t); });
+  for (auto& th : pool) th.join();
+}
 
 zg16_status spmv_device(zg16_ctx* ctx, const zg16_r1cs* r, const Fr* z, Fr* a, Fr* b, Fr* c);
 // rows of matrix k (0 = A, 1 = B, 2 = C) only

@@ -66,32 +66,41 @@ void spmv_encode_coeffs(const uint64_t* coeff, size_t nnz, std::vector<uint16_t>
   }
   codes.resize(nnz);
   *needs_full = false;
-  FrKey last = key_of(one);
-  uint16_t last_code = 0;
+  // Pass 1, over host threads: every coefficient with a fixed code (+-1, +-2^k -- nearly all of a zinc circuit)
+  // gets it; the others are marked.  Pass 2, in order: the marked ones get dictionary codes by first appearance.
+  constexpr uint16_t OTHER = 0xfffe;
+  host_parallel(nnz, [&](size_t lo, size_t hi) {
+    FrKey last = key_of(one);
+    uint16_t last_code = 0;
+    for (size_t e = lo; e < hi; e++) {
+      FrKey k;
+      memcpy(k.w, coeff + 4 * e, 32);
+      if (!(k == last)) {  // runs of equal coefficients (the ones of boolean rows) skip the look-up
+        auto it = known.find(k);
+        last_code = it != known.end() ? it->second : OTHER;
+        last = k;
+      }
+      codes[e] = last_code;
+    }
+  });
   for (size_t e = 0; e < nnz; e++) {
+    if (codes[e] != OTHER) continue;
     FrKey k;
     memcpy(k.w, coeff + 4 * e, 32);
-    if (k == last) {  // runs of equal coefficients (the ones of boolean rows) skip the table look-up
-      codes[e] = last_code;
-      continue;
-    }
-    uint16_t code;
     auto it = known.find(k);
     if (it != known.end()) {
-      code = it->second;
-    } else if (table.size() < SPMV_CODE_FULL) {
-      code = (uint16_t)table.size();
+      codes[e] = it->second;
+    } else if (table.size() < OTHER) {
+      const uint16_t code = (uint16_t)table.size();
       Fr f;
       memcpy(f.v, k.w, 32);
       table.push_back(f);
       known.emplace(k, code);
+      codes[e] = code;
     } else {
-      code = SPMV_CODE_FULL;
+      codes[e] = SPMV_CODE_FULL;
       *needs_full = true;
     }
-    codes[e] = code;
-    last = k;
-    last_code = code;
   }
 }
 
