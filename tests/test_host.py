@@ -327,3 +327,24 @@ def test_verify_proof_golden(idx):
     with pytest.raises(SynthesisError) as e:
         verify_proof(VK, raw, public + [1])
     assert e.value.status_name == "MalformedKey"
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_gloo_sharded_h_schedule(world):
+    """The three-round schedule that keeps a, b, c sharded through the whole H computation, over gloo ranks on the
+    CPU: the product's stage / exchange loop around big-integer stand-ins for the stages gives every rank its
+    cyclic slice of the oracle's H coefficients."""
+    script = os.path.join(ROOT, "tests", "gloo_hshard_worker.py")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    procs = [subprocess.Popen([sys.executable, script, str(r), str(world), str(29570 + world), "6"], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=240)[0].decode())
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "HSHARD_MATCH" in outs[0], outs[0]

@@ -134,7 +134,9 @@ ZG_D uint32_t extract_bits(const uint32_t* v, uint32_t lo, uint32_t c) {
 //                   their buckets are counted / ranked in LDS and again cost one global atomic per
 //                   (tile, bucket).  A tile that spans more buckets than LDS holds (tiny multiexps)
 //                   falls back to one atomic per entry.
-static constexpr uint32_t SORT_TERMS = 4;           // terms per lane in k_sort_count / k_sort_scatter
+static constexpr uint32_t SORT_TERMS_SMALL = 4;     // terms per lane in k_sort_count / k_sort_scatter ...
+static constexpr uint32_t SORT_TERMS_LARGE = 16;    // ... and from 2^22 terms on: a workgroup's run in a coarse bin is
+                                                    // then several 128-byte lines long, not a fraction of one
 static constexpr uint32_t SORT_MAX_COARSE = 1024;
 static constexpr uint32_t FINE_TILE = 4096;         // entries per workgroup in k_fine_*
 static constexpr uint32_t FINE_PER_LANE = FINE_TILE / 256;
@@ -143,6 +145,7 @@ static constexpr uint32_t FINE_LDS = 8192;          // LDS counters in k_fine_*
 struct SortShape {
   uint32_t shift;    // coarse bin = bucket >> shift
   uint32_t ncoarse;  // coarse bins covering the digit buckets; bins ncoarse + g count group g's unit scalars
+  uint32_t terms;    // terms per lane of k_sort_count / k_sort_scatter
 };
 
 // Calls digit(bucket, window, negative) for every non-zero signed digit of term i and one(group) if
@@ -150,14 +153,21 @@ struct SortShape {
 template <class F, class FD, class FO>
 ZG_D void term_digits(const JobTable<F>& jt, const MsmShape& sh, uint32_t i, FD digit, FO one) {
   const int j = find_job(jt, i);
-  const Fr s = from_mont(load_scalar(jt, i, j));
-  uint32_t rest = 0;
+  // zero and one -- four fifths of a zinc witness -- are recognised in Montgomery form, before the product that
+  // takes a scalar out of it
+  const Fr sm = load_scalar(jt, i, j);
+  uint32_t nz = 0, n1 = 0;
 #pragma unroll
-  for (int k = 1; k < 8; k++) rest |= s.v[k];
-  if (rest == 0 && s.v[0] <= 1) {
-    if (s.v[0]) one(jt.group[j]);
+  for (int k = 0; k < 8; k++) {
+    nz |= sm.v[k];
+    n1 |= sm.v[k] ^ FrParams::one(k);
+  }
+  if (nz == 0) return;
+  if (n1 == 0) {
+    one(jt.group[j]);
     return;
   }
+  const Fr s = from_mont(sm);
   const uint32_t set_base = sh.shared ? jt.group[j] * sh.f * sh.B : 0;
   uint32_t carry = 0;
   for (uint32_t w = 0; w < sh.W; w++) {
@@ -181,6 +191,7 @@ ZG_D void term_digits(const JobTable<F>& jt, const MsmShape& sh, uint32_t i, FD 
 template <class F>
 __global__ __launch_bounds__(256) void k_sort_count(JobTable<F> jt, MsmShape sh, SortShape ss,
                                                     uint32_t* __restrict__ chist, uint32_t* __restrict__ wg_hist) {
+  const uint32_t SORT_TERMS = ss.terms;
   __shared__ uint32_t lh[SORT_MAX_COARSE + MAX_JOBS];
   const uint32_t tid = threadIdx.x, nbins = ss.ncoarse + sh.G;
   for (uint32_t j = tid; j < nbins; j += 256) lh[j] = 0;
@@ -230,6 +241,7 @@ __global__ __launch_bounds__(256) void k_sort_scatter(JobTable<F> jt, MsmShape s
                                                       uint2* __restrict__ rec_final) {
   __shared__ uint32_t lh[SORT_MAX_COARSE + MAX_JOBS];     // cursor inside this workgroup's run of each bin
   __shared__ uint32_t lbase[SORT_MAX_COARSE + MAX_JOBS];  // start of that run (scanned k_sort_count histogram)
+  const uint32_t SORT_TERMS = ss.terms;
   const uint32_t tid = threadIdx.x, nbins = ss.ncoarse + sh.G;
   for (uint32_t j = tid; j < nbins; j += 256) {
     lh[j] = 0;
@@ -1001,6 +1013,8 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
   while (((sh.nb + (1u << ss.shift) - 1) >> ss.shift) > SORT_MAX_COARSE) ss.shift++;
   ss.ncoarse = (sh.nb + (1u << ss.shift) - 1) >> ss.shift;
   const uint32_t nbins = ss.ncoarse + sh.G;
+  ss.terms = n >= ((size_t)1 << 22) ? SORT_TERMS_LARGE : SORT_TERMS_SMALL;
+  const uint32_t SORT_TERMS = ss.terms;
 
   // scratch layout
   auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };

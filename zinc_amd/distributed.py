@@ -122,6 +122,20 @@ def prove_sharded(ctx, key, mat, z_in_ptr, z_aux_ptr, on_device, pk_view, r_mont
 
 
 # ---- transforms sharded through the whole H computation ----------------------------------------------
+def run_sharded_stages(stage, work, got, world, device=None, after_exchange=None):
+    """The stage / exchange loop of a proof whose transforms are sharded (zg16_hshard_stage's contract): call
+    stage(k) for k = 0..3; it leaves n vectors to exchange in work[0..n); each goes through one equal-split
+    all-to-all into got[v].  work, got: (3, L, 4) int64 tensors; stage is the library call on the GPU and a CPU
+    stand-in in the gloo rehearsal (tests/gloo_hshard_worker.py)."""
+    for k in range(4):
+        n = stage(k)
+        for v in range(n):
+            # (with gloo the exchange is staged through the host and lands back in the source tensor)
+            got[v].copy_(_all_to_all(work[v], world, device))
+        if n and after_exchange is not None:
+            after_exchange()
+
+
 class ShardedProver:
     """One rank of a proof whose transforms are spread over the GPUs as well (zg16_hshard_*): this rank's key
     shard (h cyclic, the other queries by point range), its stage object and its two exchange buffers."""
@@ -143,19 +157,19 @@ class ShardedProver:
 
     def prove(self, z_in_ptr, z_aux_ptr, on_device, r_mont, s_mont):
         """Returns the lib.Proof on rank 0 and None elsewhere."""
+        import torch
         L = self.ctx._lib
-        n = C.c_int()
-        for stage in range(4):
-            _check(self.ctx.handle, L.zg16_hshard_stage(self.hs, stage, C.c_void_p(z_in_ptr), C.c_void_p(z_aux_ptr),
+
+        def stage(k):
+            n = C.c_int()
+            _check(self.ctx.handle, L.zg16_hshard_stage(self.hs, k, C.c_void_p(z_in_ptr), C.c_void_p(z_aux_ptr),
                                                         int(on_device), C.c_void_p(self.work.data_ptr()),
                                                         C.c_void_p(self.got.data_ptr()), C.byref(n)))
-            for v in range(n.value):
-                # (with gloo the exchange is staged through the host and lands back in the source tensor)
-                self.got[v].copy_(_all_to_all(self.work[v], self.world, self.device))
-            if n.value:
-                # the library's kernels run on its own streams: torch's copies must have landed before the next stage
-                import torch
-                torch.cuda.synchronize(self.device)
+            return n.value
+
+        # the library's kernels run on its own streams: torch's copies must have landed before the next stage
+        run_sharded_stages(stage, self.work, self.got, self.world, self.device,
+                           after_exchange=lambda: torch.cuda.synchronize(self.device))
         part = _lib.Partial()
         _check(self.ctx.handle, L.zg16_hshard_finish(self.hs, C.byref(part)))
         parts = gather_partials(part, self.world, self.rank, self.device)
