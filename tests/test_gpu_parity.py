@@ -870,7 +870,8 @@ def test_generate_parameters_golden(gpu_ctx, idx):
 @pytest.mark.gpu
 def test_generate_parameters_vs_host_and_unconstrained(gpu_ctx):
     from zinc_amd import workload
-    circ = workload.SyntheticCircuit(1 << 13, n_pub=5, seed=(4, 3, 2, 1))
+    # (2^15 rows: ONE occurs in more rows than one segment of the transposed product holds)
+    circ = workload.SyntheticCircuit(1 << 15, n_pub=5, seed=(4, 3, 2, 1))
     toxic = dict(k1=5, k2=7, alpha=11, beta=13, gamma=17, delta=19, tau=0x1234567)
     got = workload.generate_parameters(gpu_ctx, circ, toxic)
     want = workload.generate_parameters_host(gpu_ctx, circ, toxic)

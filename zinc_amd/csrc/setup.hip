@@ -105,10 +105,30 @@ __global__ __launch_bounds__(256) void k_setup_combine(const Fr* __restrict__ a,
   out[v] = mul(t, v < n_in ? gamma_inv : delta_inv);
 }
 
-// The transpose of one CSR matrix as a device-resident R1csMatrix whose "rows" are the variables (inputs then aux)
-// and whose "columns" are the constraint rows.
+// A variable that occurs in very many rows (ONE does, in about every boolean row) would be one endless "row" of the
+// transposed matrix for a single wavefront; such a row is cut into segments of SEGMENT terms, the segments after the
+// first become extra rows behind the nv real ones, and k_fold_segments adds them back.
+static constexpr uint32_t SEGMENT = 8192;
+struct SegmentList {
+  std::vector<uint32_t> owner;  // owner[i]: the variable extra row nv + i belongs to (ascending)
+};
+
+// out[owner] += out[nv + i] for every extra row, one thread per matrix (there are few extra rows)
+__global__ void k_fold_segments(Fr* a, Fr* b, Fr* c, const uint32_t* __restrict__ owner_a, uint32_t na,
+                                const uint32_t* __restrict__ owner_b, uint32_t nb_, const uint32_t* __restrict__ owner_c,
+                                uint32_t nc, uint32_t nv) {
+  Fr* outs[3] = {a, b, c};
+  const uint32_t* owners[3] = {owner_a, owner_b, owner_c};
+  const uint32_t counts[3] = {na, nb_, nc};
+  const uint32_t k = threadIdx.x;
+  if (k >= 3) return;
+  for (uint32_t i = 0; i < counts[k]; i++) outs[k][owners[k][i]] = add(outs[k][owners[k][i]], outs[k][nv + i]);
+}
+
+// The transpose of one CSR matrix as a device-resident R1csMatrix whose "rows" are the variables (inputs then aux,
+// then the extra segment rows) and whose "columns" are the constraint rows.
 static zg16_status upload_transposed(zg16_ctx* ctx, const zg16_csr& m, size_t n_rows, size_t n_in, size_t n_aux, int which,
-                                     R1csMatrix* out) {
+                                     R1csMatrix* out, SegmentList* segs) {
   const size_t nv = n_in + n_aux;
   if (!m.row_ptr) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "matrix %d has no row_ptr", which);
   const size_t nnz = (size_t)m.row_ptr[n_rows];
@@ -128,8 +148,10 @@ static zg16_status upload_transposed(zg16_ctx* ctx, const zg16_csr& m, size_t n_
     if (!flat(m.col[e], &v)) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "matrix %d names a variable the circuit does not have", which);
     vp[v + 1]++;
   }
+  // entries stay grouped by variable in the transposed arrays; a row boundary is added after every SEGMENT terms
+  std::vector<uint32_t> count(nv);
   for (size_t v = 0; v < nv; v++) {
-    if (vp[v + 1] > SPMV_LONG_ROW) longs.push_back((uint32_t)v);
+    count[v] = vp[v + 1];
     vp[v + 1] += vp[v];
   }
   std::vector<uint32_t> cursor(vp.begin(), vp.end() - 1);
@@ -143,6 +165,37 @@ static zg16_status upload_transposed(zg16_ctx* ctx, const zg16_csr& m, size_t n_
       memcpy(&co[4 * (size_t)pos], m.coeff + 4 * e, 32);
     }
   }
+  // row offsets: the nv real rows (each at most SEGMENT terms long), then the extra segments.  The entries of one
+  // variable are contiguous, so a real row followed by its extra rows covers them in order -- but extra rows sit
+  // behind ALL real rows, so the entries are regrouped: real parts first, segments after.
+  std::vector<uint32_t> rp(1, 0), src_lo, src_hi;
+  for (size_t v = 0; v < nv; v++) {
+    const uint32_t head = count[v] < SEGMENT ? count[v] : SEGMENT;
+    src_lo.push_back(vp[v]);
+    src_hi.push_back(vp[v] + head);
+    rp.push_back(rp.back() + head);
+  }
+  for (size_t v = 0; v < nv; v++)
+    for (uint32_t done = SEGMENT; done < count[v]; done += SEGMENT) {
+      const uint32_t len = count[v] - done < SEGMENT ? count[v] - done : SEGMENT;
+      src_lo.push_back(vp[v] + done);
+      src_hi.push_back(vp[v] + done + len);
+      rp.push_back(rp.back() + len);
+      segs->owner.push_back((uint32_t)v);
+    }
+  if (!segs->owner.empty()) {
+    std::vector<uint32_t> rows2(nnz);
+    std::vector<uint64_t> co2(4 * nnz);
+    for (size_t r = 0; r + 1 < rp.size(); r++) {
+      memcpy(&rows2[rp[r]], &rows[src_lo[r]], (size_t)(src_hi[r] - src_lo[r]) * 4);
+      memcpy(&co2[4 * (size_t)rp[r]], &co[4 * (size_t)src_lo[r]], (size_t)(src_hi[r] - src_lo[r]) * 32);
+    }
+    rows.swap(rows2);
+    co.swap(co2);
+  }
+  vp.swap(rp);
+  for (size_t r = 0; r + 1 < vp.size(); r++)
+    if (vp[r + 1] - vp[r] > SPMV_LONG_ROW) longs.push_back((uint32_t)r);
   std::vector<uint16_t> codes;
   std::vector<Fr> table;
   bool needs_full = false;
@@ -196,21 +249,54 @@ static zg16_status generate_parameters(zg16_ctx* ctx, const zg16_r1cs_view* v, c
 
   // transposed matrices (a temporary zg16_r1cs whose rows are the variables), released on every exit
   std::unique_ptr<zg16_r1cs, void (*)(zg16_r1cs*)> t(new zg16_r1cs(), r1cs_destroy);
-  t->n_rows = nv;
   t->n_in = m;  // (the "witness" of the transposed product is the vector L of m entries)
   t->n_aux = 0;
   t->log_m = ceil_log2(nv);
   const zg16_csr* mats[3] = {&v->a, &v->b, &v->c};
-  for (int k = 0; k < 3; k++) ZG_TRY(upload_transposed(ctx, *mats[k], n_rows, n_in, n_aux, k, &t->m[k]));
+  SegmentList segs[3];
+  size_t rows_t = nv;  // rows of the widest transposed matrix: the variables plus its extra segments
+  for (int k = 0; k < 3; k++) {
+    ZG_TRY(upload_transposed(ctx, *mats[k], n_rows, n_in, n_aux, k, &t->m[k], &segs[k]));
+    rows_t = std::max(rows_t, nv + segs[k].owner.size());
+  }
+  // (a matrix with fewer extra rows than the widest gets empty rows up to rows_t: its row offsets are padded)
+  for (int k = 0; k < 3; k++) {
+    const size_t have = nv + segs[k].owner.size();
+    if (have == rows_t) continue;
+    std::vector<uint32_t> rp(rows_t + 1);
+    ZG_HIP(ctx, hipMemcpy(rp.data(), t->m[k].row_ptr, (have + 1) * 4, hipMemcpyDeviceToHost));
+    for (size_t r = have + 1; r <= rows_t; r++) rp[r] = rp[have];
+    (void)hipFree(t->m[k].row_ptr);
+    t->m[k].row_ptr = nullptr;
+    ZG_HIP(ctx, hipMalloc((void**)&t->m[k].row_ptr, (rows_t + 1) * 4));
+    ZG_HIP(ctx, hipMemcpy(t->m[k].row_ptr, rp.data(), (rows_t + 1) * 4, hipMemcpyHostToDevice));
+  }
+  t->n_rows = rows_t;
 
-  // device work area: L (m), a_s, b_s, c_s, icl_s (nv each), h_s (m)
+  // device work area: L (m), a_s, b_s, c_s (rows_t each), icl_s (nv), h_s (m), the owners of the extra rows
+  const size_t n_extra = segs[0].owner.size() + segs[1].owner.size() + segs[2].owner.size();
   Fr* work = nullptr;
-  ZG_HIP(ctx, hipMalloc((void**)&work, (2 * m + 4 * nv) * sizeof(Fr)));
+  ZG_HIP(ctx, hipMalloc((void**)&work, (2 * m + 3 * rows_t + nv) * sizeof(Fr) + (n_extra + 1) * 4));
   std::unique_ptr<Fr, void (*)(Fr*)> work_guard(work, [](Fr* p) { (void)hipFree(p); });
-  Fr *lag = work, *a_s = lag + m, *b_s = a_s + nv, *c_s = b_s + nv, *icl_s = c_s + nv, *h_s = icl_s + nv;
+  Fr *lag = work, *a_s = lag + m, *b_s = a_s + rows_t, *c_s = b_s + rows_t, *icl_s = c_s + rows_t, *h_s = icl_s + nv;
+  uint32_t* owners = (uint32_t*)(h_s + m);
+  uint32_t* owner_k[3];
+  {
+    size_t at = 0;
+    for (int k = 0; k < 3; k++) {
+      owner_k[k] = owners + at;
+      if (!segs[k].owner.empty())
+        ZG_HIP(ctx, hipMemcpy(owner_k[k], segs[k].owner.data(), segs[k].owner.size() * 4, hipMemcpyHostToDevice));
+      at += segs[k].owner.size();
+    }
+  }
   ZG_TRY(pow_table_device(ctx, lag, m, tau, one));
   ZG_TRY(ntt_device(ctx, lag, log_m, true, false));  // L_j(tau)
   ZG_TRY(spmv_device(ctx, t.get(), lag, a_s, b_s, c_s));
+  if (n_extra)
+    k_fold_segments<<<1, 64, 0, ctx->stream>>>(a_s, b_s, c_s, owner_k[0], (uint32_t)segs[0].owner.size(), owner_k[1],
+                                                (uint32_t)segs[1].owner.size(), owner_k[2], (uint32_t)segs[2].owner.size(),
+                                                (uint32_t)nv);
   k_setup_combine<<<(unsigned)((nv + 255) / 256), 256, 0, ctx->stream>>>(a_s, b_s, c_s, icl_s, (uint32_t)nv, (uint32_t)n_in, alpha,
                                                                        beta, gamma_inv, delta_inv);
   // h[i] = g1 * tau^i (tau^m - 1) / delta
