@@ -124,8 +124,8 @@ ZG_D uint32_t extract_bits(const uint32_t* v, uint32_t lo, uint32_t c) {
 // bucket is irrelevant (group addition is exact), so this is a two-level counting sort whose global
 // atomics are per (workgroup, bin) instead of per entry:
 //   k_sort_count    terms -> digits -> LDS histogram of coarse bins (bucket >> shift, at most
-//                   SORT_MAX_COARSE of them) -> one global add per non-empty bin per workgroup
-//   k_scan_coarse   exclusive scan of the coarse bins (one workgroup)
+//                   SORT_MAX_COARSE of them) -> the workgroup's row of the (bin, workgroup) histogram
+//   k_coarse_offsets  coarse bin starts, read off the scanned per-workgroup histograms
 //   k_sort_scatter  same digits again; a scan of the per-workgroup histograms k_sort_count left behind gives
 //                   the workgroup its run in every coarse bin, and it writes its entries there (ranks by LDS
 //                   atomics, no global atomic at all).  Unit scalars go straight to their final
@@ -148,11 +148,12 @@ struct SortShape {
   uint32_t terms;    // terms per lane of k_sort_count / k_sort_scatter
 };
 
-// Calls digit(bucket, window, negative) for every non-zero signed digit of term i and one(group) if
-// the scalar equals one.  Scalars equal to zero produce nothing.
-template <class F, class FD, class FO>
-ZG_D void term_digits(const JobTable<F>& jt, const MsmShape& sh, uint32_t i, FD digit, FO one) {
+// Term i's scalar: 0 when it is zero (the term produces nothing), 1 when it is one (the term goes to its group's
+// unit-scalar bucket), else 2 with the canonical value in *s.  *job: the job the term belongs to.
+template <class F>
+ZG_D int term_scalar(const JobTable<F>& jt, uint32_t i, Fr* s, int* job) {
   const int j = find_job(jt, i);
+  *job = j;
   // zero and one -- four fifths of a zinc witness -- are recognised in Montgomery form, before the product that
   // takes a scalar out of it
   const Fr sm = load_scalar(jt, i, j);
@@ -162,13 +163,17 @@ ZG_D void term_digits(const JobTable<F>& jt, const MsmShape& sh, uint32_t i, FD 
     nz |= sm.v[k];
     n1 |= sm.v[k] ^ FrParams::one(k);
   }
-  if (nz == 0) return;
-  if (n1 == 0) {
-    one(jt.group[j]);
-    return;
-  }
-  const Fr s = from_mont(sm);
-  const uint32_t set_base = sh.shared ? jt.group[j] * sh.f * sh.B : 0;
+  if (nz == 0) return 0;
+  if (n1 == 0) return 1;
+  *s = from_mont(sm);
+  return 2;
+}
+
+// Calls digit(bucket, window, negative) for every non-zero signed digit of the canonical scalar s of a term of
+// group `group`.
+template <class FD>
+ZG_D void scalar_digits(const MsmShape& sh, uint32_t group, const Fr& s, FD digit) {
+  const uint32_t set_base = sh.shared ? group * sh.f * sh.B : 0;
   uint32_t carry = 0;
   for (uint32_t w = 0; w < sh.W; w++) {
     uint32_t d = extract_bits(s.v, w * sh.c, sh.c) + carry;
@@ -188,9 +193,20 @@ ZG_D void term_digits(const JobTable<F>& jt, const MsmShape& sh, uint32_t i, FD 
   }
 }
 
+// Calls digit(bucket, window, negative) for every non-zero signed digit of term i and one(group) if
+// the scalar equals one.  Scalars equal to zero produce nothing.
+template <class F, class FD, class FO>
+ZG_D void term_digits(const JobTable<F>& jt, const MsmShape& sh, uint32_t i, FD digit, FO one) {
+  Fr s;
+  int j;
+  const int kind = term_scalar(jt, i, &s, &j);
+  if (kind == 1) one(jt.group[j]);
+  if (kind == 2) scalar_digits(sh, jt.group[j], s, digit);
+}
+
 template <class F>
 __global__ __launch_bounds__(256) void k_sort_count(JobTable<F> jt, MsmShape sh, SortShape ss,
-                                                    uint32_t* __restrict__ chist, uint32_t* __restrict__ wg_hist) {
+                                                    uint32_t* __restrict__ wg_hist) {
   const uint32_t SORT_TERMS = ss.terms;
   __shared__ uint32_t lh[SORT_MAX_COARSE + MAX_JOBS];
   const uint32_t tid = threadIdx.x, nbins = ss.ncoarse + sh.G;
@@ -207,49 +223,44 @@ __global__ __launch_bounds__(256) void k_sort_count(JobTable<F> jt, MsmShape sh,
   // bin-major, so that one exclusive scan over the whole array gives every (bin, workgroup) its run's start
   for (uint32_t j = tid; j < nbins; j += 256) {
     wg_hist[(size_t)j * gridDim.x + blockIdx.x] = lh[j];
-    if (lh[j]) atomicAdd(&chist[j], lh[j]);
   }
 }
 
-// One workgroup: coff = exclusive scan of chist[0..nbins) (coff[nbins] = total), and hist[nb + g] = number of
-// unit scalars of group g so that the bucket scan places them too.
-__global__ __launch_bounds__(1024) void k_scan_coarse(const uint32_t* __restrict__ chist, uint32_t ncoarse, uint32_t G,
-                                                      uint32_t* __restrict__ coff, uint32_t* __restrict__ hist,
-                                                      uint32_t nb) {
-  __shared__ uint32_t part[1024];
-  const uint32_t tid = threadIdx.x, nbins = ncoarse + G;
-  // nbins <= SORT_MAX_COARSE + MAX_JOBS: two counters per lane cover it
-  const uint32_t v0 = 2 * tid < nbins ? chist[2 * tid] : 0, v1 = 2 * tid + 1 < nbins ? chist[2 * tid + 1] : 0;
-  part[tid] = v0 + v1;
-  __syncthreads();
-  for (uint32_t d = 1; d < 1024; d <<= 1) {
-    const uint32_t x = tid >= d ? part[tid - d] : 0;
-    __syncthreads();
-    part[tid] += x;
-    __syncthreads();
+// The coarse offsets fall out of the scanned per-workgroup histograms: bin j starts where its first workgroup's run
+// starts.  coff[nbins] = total, and hist[nb + g] = number of unit scalars of group g so that the bucket scan places
+// them too.  (A global histogram kept by atomics beside the per-workgroup ones cost k_sort_count half its time: a
+// thousand workgroups adding to the same few hundred counters.)
+__global__ __launch_bounds__(256) void k_coarse_offsets(const uint32_t* __restrict__ wg_off, uint32_t sgrid, uint32_t n_wgh,
+                                                        uint32_t ncoarse, uint32_t G, uint32_t* __restrict__ coff,
+                                                        uint32_t* __restrict__ hist, uint32_t nb) {
+  const uint32_t nbins = ncoarse + G;
+  for (uint32_t j = threadIdx.x; j <= nbins; j += 256) coff[j] = j < nbins ? wg_off[(size_t)j * sgrid] : wg_off[n_wgh];
+  if (threadIdx.x < G) {
+    const uint32_t j = ncoarse + threadIdx.x;
+    const uint32_t end = j + 1 < nbins ? wg_off[(size_t)(j + 1) * sgrid] : wg_off[n_wgh];
+    hist[nb + threadIdx.x] = end - wg_off[(size_t)j * sgrid];
   }
-  const uint32_t excl = tid ? part[tid - 1] : 0;
-  if (2 * tid < nbins) coff[2 * tid] = excl;
-  if (2 * tid + 1 < nbins) coff[2 * tid + 1] = excl + v0;
-  if (tid == 1023) coff[nbins] = part[1023];
-  if (tid < G) hist[nb + tid] = chist[ncoarse + tid];
 }
 
+// The coarse scatter: every lane stores its entries straight to their bins' runs (ranks by LDS atomics).
+// (Measured and dropped: ordering a chunk's entries by bin in LDS first -- count, scan, place, then copy out by
+// consecutive lanes -- so that runs are written as whole lines.  It does bring the bytes written down from 2.0x the
+// entry bytes, and it is half as fast again: 0.97 against 0.66 ms of sort per 2^20-row proof, 11.0 against 7.7 ms at
+// 2^24.  The scatter is bound by its digit arithmetic, LDS atomics and barriers, not by HBM writes.)
 template <class F>
 __global__ __launch_bounds__(256) void k_sort_scatter(JobTable<F> jt, MsmShape sh, SortShape ss,
-                                                      const uint32_t* __restrict__ wg_off, uint2* __restrict__ rec_coarse,
-                                                      uint2* __restrict__ rec_final) {
+                                                             const uint32_t* __restrict__ wg_off,
+                                                             uint2* __restrict__ rec_coarse, uint2* __restrict__ rec_final) {
   __shared__ uint32_t lh[SORT_MAX_COARSE + MAX_JOBS];     // cursor inside this workgroup's run of each bin
   __shared__ uint32_t lbase[SORT_MAX_COARSE + MAX_JOBS];  // start of that run (scanned k_sort_count histogram)
-  const uint32_t SORT_TERMS = ss.terms;
   const uint32_t tid = threadIdx.x, nbins = ss.ncoarse + sh.G;
   for (uint32_t j = tid; j < nbins; j += 256) {
     lh[j] = 0;
     lbase[j] = wg_off[(size_t)j * gridDim.x + blockIdx.x];
   }
   __syncthreads();
-  const uint32_t tile = blockIdx.x * (256 * SORT_TERMS);
-  for (uint32_t k = 0; k < SORT_TERMS; k++) {
+  const uint32_t tile = blockIdx.x * (256 * ss.terms);
+  for (uint32_t k = 0; k < ss.terms; k++) {
     const uint32_t i = tile + k * 256 + tid;
     if (i < sh.n)
       term_digits(
@@ -1008,8 +1019,12 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
     return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "multiexp result block too large");
   const uint32_t ncount = sh.nb + sh.G;  // counters: digit buckets, then one unit-scalar bucket per group
 
+  // Coarse bins: about 256 (a workgroup's run in a bin is then a few lines long; 1024 bins measured 5 % slower at
+  // 2^24 rows), as long as two bins' buckets still fit the LDS counters of the fine passes.
   SortShape ss;
+  static const uint32_t want_bins = getenv("ZG16_SORT_BINS") ? (uint32_t)atoi(getenv("ZG16_SORT_BINS")) : 256;
   ss.shift = 7;
+  while (((sh.nb + (1u << ss.shift) - 1) >> ss.shift) > want_bins && (4u << ss.shift) <= FINE_LDS) ss.shift++;
   while (((sh.nb + (1u << ss.shift) - 1) >> ss.shift) > SORT_MAX_COARSE) ss.shift++;
   ss.ncoarse = (sh.nb + (1u << ss.shift) - 1) >> ss.shift;
   const uint32_t nbins = ss.ncoarse + sh.G;
@@ -1022,7 +1037,6 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
   const size_t o_hist = o;   o += align((size_t)ncount * 4);
   const size_t o_off = o;    o += align((size_t)(ncount + 1) * 4);
   const size_t o_cur = o;    o += align((size_t)ncount * 4);
-  const size_t o_chist = o;  o += align((size_t)nbins * 4);
   const size_t o_coff = o;   o += align((size_t)(nbins + 1) * 4);
   const size_t o_err = o;    o += 256;  // [0] identity-base flag, [2] number of heavy buckets
   const size_t o_zero_end = o;
@@ -1060,7 +1074,6 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
   uint32_t* hist = (uint32_t*)(base + o_hist);
   uint32_t* off = (uint32_t*)(base + o_off);
   uint32_t* cursor = (uint32_t*)(base + o_cur);
-  uint32_t* chist = (uint32_t*)(base + o_chist);
   uint32_t* coff = (uint32_t*)(base + o_coff);
   uint32_t* err = (uint32_t*)(base + o_err);
   uint2* rec0 = (uint2*)(base + o_rec0);
@@ -1079,12 +1092,12 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
   {
     KernelTimer kt(ctx, K_MSM_DIGITS, (double)n, st);
     const unsigned fgrid = (unsigned)((max_entries + FINE_TILE - 1) / FINE_TILE);
-    k_sort_count<F><<<sgrid, 256, 0, st>>>(jt, sh, ss, chist, wg_hist);
-    k_scan_coarse<<<1, 1024, 0, st>>>(chist, ss.ncoarse, sh.G, coff, hist, sh.nb);
+    k_sort_count<F><<<sgrid, 256, 0, st>>>(jt, sh, ss, wg_hist);
     // exclusive scan of the (bin, workgroup) histogram, in place: every workgroup's run start in every bin
     k_scan_local<<<wg_tiles, 256, 0, st>>>(wg_hist, (uint32_t)n_wgh, wg_hist, wg_tiles_sum);
     k_scan_tiles<<<1, 1024, 0, st>>>(wg_tiles_sum, wg_tiles);
     k_scan_fixup<<<(unsigned)((n_wgh + 1 + 255) / 256), 256, 0, st>>>(wg_hist, wg_hist, (uint32_t)n_wgh, wg_tiles_sum, wg_tiles);
+    k_coarse_offsets<<<1, 256, 0, st>>>(wg_hist, sgrid, (uint32_t)n_wgh, ss.ncoarse, sh.G, coff, hist, sh.nb);
     k_sort_scatter<F><<<sgrid, 256, 0, st>>>(jt, sh, ss, wg_hist, rec0, rec);
     k_fine_count<<<fgrid, 256, 0, st>>>(rec0, coff, ss, hist);
     k_scan_local<<<ntiles, 256, 0, st>>>(hist, ncount, off, tiles);
