@@ -1,36 +1,37 @@
-"""Timeline of one prove step from a rocprofv3 --kernel-trace csv: kernels per queue with start/end in us.
-
-    python tools/timeline.py <kernel_trace.csv> [step_from_end]
-A step starts at the first k_spmv_* launch; steps are counted from the end of the trace.
-"""
+#!/usr/bin/env python3
+"""Timeline of the last proof in a rocprofv3 --kernel-trace CSV: every kernel's start and duration relative to the
+proof's first kernel, by hardware queue, plus how many microseconds of the proof had 0, 1, 2, ... kernels running.
+usage: timeline.py kernel_trace.csv [first-kernel-substring]"""
 import csv
 import re
 import sys
 
+rows = list(csv.DictReader(open(sys.argv[1])))
+first = sys.argv[2] if len(sys.argv) > 2 else "k_spmv_short"
+ks = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?")) for r in rows]
+ks.sort()
+starts = [i for i, k in enumerate(ks) if first in k[2]]
+# a proof begins shortly before its row evaluation (the witness multiexps start first): take the window between the
+# last two row evaluations
+lo_i, hi_i = starts[-2], starts[-1]
+t_lo = ks[lo_i][0]
+window = [k for k in ks if t_lo - 300_000 <= k[0] < ks[hi_i][0] - 300_000]
+t0 = min(k[0] for k in window)
+
 
 def short(name):
-    name = re.sub(r"^void ", "", name).replace("zg::", "")
-    name = re.sub(r"Fp<FqParams\s*>", "Fq", name)
-    return name.split("(")[0]
+    name = re.sub(r"\(.*", "", name).replace("void zg::", "").replace("zg::", "")
+    return name.replace("Fp<FqParams> ", "G1").replace("Fp<FqParams>", "G1")[:30]
 
 
-def main(path, back=1):
-    rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), r["Queue_Id"]) for r in csv.DictReader(open(path))]
-    rows.sort()
-    # step boundaries: a k_spmv_* launch more than 0.1 ms after the previous one opens a prove
-    starts, last = [], -10**18
-    for i, r in enumerate(rows):
-        if r[2].startswith("k_spmv"):
-            if r[0] - last > 100000:
-                starts.append(i)
-            last = r[0]
-    i0 = starts[-back]
-    i1 = starts[-back + 1] if back > 1 else len(rows)
-    t0 = rows[i0][0]
-    queues = sorted({r[3] for r in rows[i0:i1]})
-    for s, e, k, q in rows[i0:i1]:
-        print("%8.1f %8.1f  %7.1f  q%-2d %s" % ((s - t0) / 1e3, (e - t0) / 1e3, (e - s) / 1e3, queues.index(q), k))
-
-
-if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+queues = sorted({k[3] for k in window})
+print("queues:", queues)
+for s, e, n, q in window:
+    print("%9.1f us  +%8.1f us  q%-3s %s%s" % ((s - t0) / 1e3, (e - s) / 1e3, q, "    " * queues.index(q), short(n)))
+events = sorted([(s, 1) for s, e, n, q in window] + [(e, -1) for s, e, n, q in window])
+depth, last, hist = 0, t0, {}
+for t, d in events:
+    hist[depth] = hist.get(depth, 0) + (t - last)
+    depth, last = depth + d, t
+print("span %.1f us; time with n kernels running:" % ((last - t0) / 1e3),
+      {n: round(v / 1e3, 1) for n, v in sorted(hist.items())})
