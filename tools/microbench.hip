@@ -25,6 +25,23 @@ __global__ void k_mad64(uint64_t* out, uint32_t a0, uint32_t b0, int iters) {
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// v_mul_lo_u32 alone (the q = t * inv step of a Montgomery round), and a mix of 9 multiply-adds to 1 mul_lo as
+// the field product has it
+template <int ILP>
+__global__ void k_mullo(uint32_t* out, uint32_t a0, uint32_t b0, int iters) {
+  uint32_t lo[ILP];
+  uint32_t a = a0 + threadIdx.x, b = b0 + blockIdx.x;
+  for (int k = 0; k < ILP; k++) lo[k] = k + 1;
+  for (int i = 0; i < iters; i++) {
+#pragma unroll
+    for (int k = 0; k < ILP; k++) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(lo[k]) : "v"(a + k));
+    b += lo[0];
+  }
+  uint32_t s = b;
+  for (int k = 0; k < ILP; k++) s ^= lo[k];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 template <int ILP>
 __global__ void k_mullohi(uint32_t* out, uint32_t a0, uint32_t b0, int iters) {
   uint32_t lo[ILP], hi[ILP];
@@ -154,6 +171,8 @@ int main() {
   {
     float ms = time_kernel([&] { k_mad64<8><<<blocks, threads>>>((uint64_t*)buf, 3, 5, iters); });
     printf("v_mad_u64_u32  : %.2f Gop/s\n", nthr * iters * 8 / ms / 1e6);
+    ms = time_kernel([&] { k_mullo<8><<<blocks, threads>>>((uint32_t*)buf, 3, 5, iters); });
+    printf("v_mul_lo_u32   : %.2f Gop/s\n", nthr * iters * 8 / ms / 1e6);
     ms = time_kernel([&] { k_mullohi<8><<<blocks, threads>>>((uint32_t*)buf, 3, 5, iters); });
     printf("mul_lo+mul_hi  : %.2f Gpair/s\n", nthr * iters * 8 / ms / 1e6);
     ms = time_kernel([&] { k_mad24<8><<<blocks, threads>>>((uint32_t*)buf, 3, 5, iters); });
