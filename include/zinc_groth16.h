@@ -162,7 +162,10 @@ zg16_status zg16_r1cs_density(const zg16_r1cs* r1cs, size_t* a_aux, size_t* b_in
  * zg16_cache_clear, by zg16_ctx_destroy, or when newer entries push them out (least recently used first; at most
  * ZG16_CACHE_KEYS keys, default 4, and ZG16_CACHE_CIRCUITS circuits, default 16, per context; a key that does not
  * fit beside the cached ones evicts them).  A key handle stays valid at least until the next zg16_pk_cached call
- * on its context, a circuit handle until the next zg16_r1cs_cached call. */
+ * on its context, a circuit handle until the next zg16_r1cs_cached call.
+ * The default context is one object for every thread that asks, and a context is used by one thread at a time:
+ * a host with several proving threads serialises each whole look-up / prove sequence on it (the Rust, C++ and
+ * Python create_proof bindings hold a process-wide lock for the call), or gives each thread a context of its own. */
 zg16_status zg16_default_ctx(int device_id, zg16_ctx** out);
 void        zg16_shutdown(void);
 zg16_status zg16_pk_cached(zg16_ctx* ctx, const zg16_pk_view* view, int full_digest, zg16_pk** out,

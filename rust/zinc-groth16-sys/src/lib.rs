@@ -173,10 +173,17 @@ unsafe fn resident_key(ctx: *mut zg16_ctx, params: &Parameters<Bn256>) -> Result
     Ok(pk)
 }
 
+/// (`Mutex::new` in a static needs Rust 1.63; with an older toolchain wrap it in `lazy_static!`, which zinc-vm
+/// already depends on.)
+static PROVE_LOCK: std::sync::Mutex<()> = std::sync::Mutex::new(());
+
 /// Same signature shape and semantics as bellman's `create_proof`, plus `circuit_id`: bytes that name the circuit
 /// (e.g. a digest of the bytecode and the method name; its structure does not depend on the inputs).  Once the
 /// library holds the matrices of a named circuit, synthesis runs in witness-only mode.
 pub fn create_proof_named<C: Circuit<Bn256>>(circuit: C, params: &Parameters<Bn256>, r: Fr, s: Fr, circuit_id: Option<&[u8]>) -> Result<Proof<Bn256>, SynthesisError> {
+    // The default context, its caches and the handles they hand out are shared by every thread of the process
+    // (zinc-tester runs its cases on a rayon pool): one proof at a time goes through here.
+    let _one_proof_at_a_time = PROVE_LOCK.lock().unwrap_or_else(|poisoned| poisoned.into_inner());
     unsafe {
         let mut ctx = std::ptr::null_mut();
         let st = zg16_default_ctx(0, &mut ctx);

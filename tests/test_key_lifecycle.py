@@ -70,6 +70,40 @@ def test_create_proof_reuses_key_and_circuit():
     assert ctx.cache_stats()["keys"] == 0
 
 
+def test_threads_share_the_default_context(monkeypatch):
+    """Several host threads proving through create_proof at once (zinc-tester runs its cases on a thread pool): the
+    default context is one object for all of them, and with room for a single key every proof evicts the other
+    thread's key -- each call still returns its own fixture's proof."""
+    import threading
+    import zinc_amd
+    from zinc_amd.groth16 import Parameters, create_proof
+    monkeypatch.setenv("ZG16_CACHE_KEYS", "1")
+    zinc_amd.Context.default(0).cache_clear()
+    fxs = [golden("prove_tiny_%d.json" % i) for i in (1, 2, 3)]
+    params = [Parameters.from_points(FixtureKey(fx)) for fx in fxs]
+    failures = []
+
+    def worker(k):
+        try:
+            for _ in range(6):
+                fx = fxs[k]
+                got = create_proof(FixtureCircuit(fx), params[k], int(fx["r"], 16), int(fx["s"], 16),
+                                   circuit_id=b"threads/%d" % k)
+                if got.as_tuple() != fixture_proof(fx):
+                    failures.append((k, "wrong proof"))
+        except Exception as e:   # a failure in a thread must fail the test, not vanish
+            failures.append((k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not failures, failures
+    assert zinc_amd.Context.default(0).cache_stats()["evictions"] > 0
+    zinc_amd.Context.default(0).cache_clear()
+
+
 def test_cache_evicts_least_recently_used(monkeypatch):
     import zinc_amd
     from zinc_amd.groth16 import Parameters, create_proof

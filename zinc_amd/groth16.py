@@ -9,6 +9,7 @@ This module keeps those names and meanings -- `ProvingAssignment.alloc / alloc_i
 in the HIP library through the C ABI (include/zinc_groth16.h).
 """
 import ctypes as C
+import threading
 import secrets
 
 import numpy as np
@@ -515,6 +516,11 @@ def prove_from_evals(ctx, dev_key, dev_r1cs, a, b, c, z_in, z_aux, r_mont, s_mon
     return Proof(raw)
 
 
+# The default context, its caches and the handles they hand out are shared by every thread of the process: one
+# create_proof at a time uses them.
+_default_ctx_lock = threading.RLock()
+
+
 def create_proof(circuit, params, r, s, ctx=None, circuit_id=None):
     """bellman `create_proof(circuit, params, r, s)`; r, s are canonical integers in Fr.
 
@@ -522,7 +528,9 @@ def create_proof(circuit, params, r, s, ctx=None, circuit_id=None):
     given), so the second proof with the same `params` skips the upload and table expansion.  circuit_id (bytes,
     e.g. a digest of the bytecode and the method) names the circuit: once its matrices are resident, synthesis runs
     against a WitnessAssignment and records no rows."""
-    ctx = ctx or Context.default()
+    if ctx is None:
+        with _default_ctx_lock:
+            return create_proof(circuit, params, r, s, Context.default(), circuit_id)
     mat = None
     if circuit_id is not None:
         mat, _ = DeviceR1CS.cached(ctx, circuit_id)

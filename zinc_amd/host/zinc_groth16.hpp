@@ -16,6 +16,7 @@
 #include <cstdint>
 #include <cstring>
 #include <stdexcept>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -173,6 +174,8 @@ class Prover {
   // between create_proof calls.  Never destroyed (the context lives until zg16_shutdown).
   static Prover& shared(int device = 0) {
     static Prover* provers[64] = {};
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
     if (device < 0 || device >= 64) throw SynthesisError(ZG16_ERR_INVALID_ARGUMENT, "bad device index");
     if (!provers[device]) {
       zg16_ctx* ctx = nullptr;
@@ -252,9 +255,12 @@ inline Proof create_proof(Circuit& circuit, const Parameters& params, const Limb
 // The same against the process-wide prover: key and matrices stay resident between calls, so a loop like
 // zinc-tester's (zinc-tester/src/runners/proof_check.rs:122) uploads each key once.  circuit_id (any bytes naming
 // the circuit, e.g. a digest of bytecode + method; empty = digest the matrices) lets later proofs of a known
-// circuit synthesize the witness only.
+// circuit synthesize the witness only.  The shared context, its caches and the handles they hand out belong to the
+// whole process, so one proof at a time goes through here: callers on several threads queue on the lock.
 inline Proof create_proof(Circuit& circuit, const Parameters& params, const Limbs& r, const Limbs& s,
                           const std::string& circuit_id = std::string(), int device = 0) {
+  static std::mutex one_proof_at_a_time;
+  std::lock_guard<std::mutex> lock(one_proof_at_a_time);
   Prover& prover = Prover::shared(device);
   const bool known = !circuit_id.empty() && prover.use_cached_circuit(circuit_id, nullptr);
   ProvingAssignment pa(known);
