@@ -191,14 +191,21 @@ def test_h_poly_golden(gpu_ctx, rows):
     assert m == fx["m"] and mont_to_ints(h, R_MOD) == [int(v, 16) for v in fx["h"]]
 
 
-@pytest.mark.parametrize("rows", [1000, 5000, (1 << 15) + 3])
-def test_h_poly_vs_cpu_oracle(gpu_ctx, rows):
+@pytest.mark.parametrize("rows", [1, 2, 3, 5, 17, 100, 1000, 1025, 2048, 2049, 4096, 4097, 5000, (1 << 15) + 3])
+def test_h_poly_vs_cpu_oracle(gpu_ctx, monkeypatch, rows):
+    """Domains of 2^0 .. 2^15: up to 2^12 the H polynomial comes from the two one-workgroup launches
+    (k_small_chains, k_small_finish), above that from the general passes; both equal the CPU restatement of
+    bellman, and the general passes give the same at the small sizes too (ZG16_SMALL_H=0)."""
     from oracle import cpu_binding as cb
     rng = np.random.default_rng(rows)
     a, b, c = (rand_fr(rng, rows) for _ in range(3))
     h, m = gpu_ctx.h_coefficients(a, b, c)
     h2, m2 = cb.h_coefficients(a, b, c, threads=8)
     assert m == m2 and np.array_equal(h, h2)
+    if rows <= 4096:
+        monkeypatch.setenv("ZG16_SMALL_H", "0")
+        h3, m3 = gpu_ctx.h_coefficients(a, b, c)
+        assert m3 == m2 and np.array_equal(h3, h2)
 
 
 # ------------------------------------------------------------------------------ multiexp

@@ -534,7 +534,9 @@ static zg16_status prove_partial_impl(zg16_ctx* ctx, const zg16_pk* pk, const zg
     Fr* abc;
     ZG_TRY(scratch_get(ctx, 4, 3 * m * sizeof(Fr), (void**)&abc));
     a = abc; b = abc + m; c = abc + 2 * m;
-    if (m > r->n_rows)
+    // the padding up to the domain size: the row evaluation writes it (rows past the last evaluate to zero); vectors
+    // that arrive evaluated are padded here
+    if (evals && m > r->n_rows)
       for (Fr* p : {a, b, c}) ZG_HIP(ctx, hipMemsetAsync(p + r->n_rows, 0, (m - r->n_rows) * sizeof(Fr), st));
   }
   const Fr* h_coeffs = h_external ? h_external : a;
@@ -569,7 +571,7 @@ static zg16_status prove_partial_impl(zg16_ctx* ctx, const zg16_pk* pk, const zg
         ZG_HIP(ctx, hipMemcpyAsync(dst[k], evals->v[k], r->n_rows * sizeof(Fr),
                                    evals->on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
     } else {
-      ZG_TRY(spmv_device(ctx, r, z, a, b, c));
+      ZG_TRY(spmv_blocks_device(ctx, r, z, a, b, c, 31, 0, 0, (uint32_t)m));  // every row in order, and the padding
     }
   }
   ZG_HIP(ctx, hipEventRecord(ev[E_SPMV], st));

@@ -626,8 +626,11 @@ __global__ __launch_bounds__(256, kMinWaves<F>) void k_split_sums(const typename
     const typename O::PtMem* row = X + (size_t)(task - r) * r;
     for (uint32_t k = lt; k < r; k += LT) O::add(acc, O::load(row + k));
   }
+  // the fold starts at the first level that still has a point in its upper half (r and h are powers of two): a
+  // second-level array of 16 points would otherwise spend two of its six dependent additions on identities
+  const uint32_t count = task < r ? h : r;
 #pragma unroll 1
-  for (uint32_t d = LT / 2; d >= 1; d >>= 1) {
+  for (uint32_t d = (count < LT ? count : LT) / 2; d >= 1; d >>= 1) {
     const typename O::Pt o = O::shfl_down(acc, d * O::LP);
     if (lt < d) O::add(acc, o);
   }

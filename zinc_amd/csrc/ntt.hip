@@ -18,6 +18,10 @@ namespace zg {
 
 static constexpr unsigned MAX_RADIX_BITS = 10;
 static constexpr unsigned TILE_ELEMS = 1024;
+// Domains up to this size have their whole H computation done by workgroups that keep a full vector in LDS
+// (2^12 elements of nine words = 144 KiB of the CU's 160).
+static constexpr unsigned SMALL_MAX_LOG = 12;
+static constexpr unsigned SMALL_THREADS = 1024;
 
 struct PassParams {
   uint32_t logR, logT;
@@ -50,6 +54,7 @@ struct NttDomain {
   Fr29* hz = nullptr;      // 32 * g^-i / (m * (g^m - 1)): the trailing factor of the fused H pipeline
   Fr29* kz = nullptr;      // [1]  1 / (m * (g^m - 1))
   Fr29* w_small[2] = {};   // [dir][512]  w_1024^e
+  Fr29* w_dom[2] = {};     // [dir][N/2]  w_N^e, only for domains the one-workgroup kernels take (N <= 2^SMALL_MAX_LOG)
   Fr* g = nullptr;         // g^i (ABI form, for the stand-alone coset_fft pre-scaling)
   Fr minv, zinv;           // 1/m, 1/(g^m - 1)
   void* block = nullptr;   // one allocation behind all of the above
@@ -230,6 +235,116 @@ __global__ __launch_bounds__(256, 4) void k_ntt_pass(const Fr* __restrict__ in, 
   }
 }
 
+// ---- small domains: a whole vector in one workgroup's LDS ---------------------------------------------
+// A proof of a small circuit is a chain of launches with almost no work in each, and the transforms were twelve of
+// them at 2^11 rows.  Up to 2^SMALL_MAX_LOG rows a vector fits one workgroup's LDS, so a workgroup runs BOTH
+// transforms of a chain without leaving the kernel (k_small_chains: one workgroup each for a, b and c) and a
+// second launch multiplies, transforms back and subtracts (k_small_finish): two launches for the H polynomial.
+// Same butterflies, same lazy bounds as k_ntt_pass (values grow by 2p per stage: below 30p after twelve).
+
+// log2(n) decimation-in-time stages over the n elements in LDS: bit-reversed positions in, natural order out.
+// w[e] = w_n^e for e < n / 2.  Ends with a barrier.
+ZG_D void small_dit(uint32_t* s, uint32_t logN, const Fr29* __restrict__ w) {
+  const uint32_t tid = threadIdx.x, N = 1u << logN;
+  uint32_t st = 0;
+  for (; st + 1 < logN; st += 2) {
+    const uint32_t h = 1u << st;
+    for (uint32_t u = tid; u < (N >> 2); u += SMALL_THREADS) {
+      const uint32_t grp = u >> st, pos = u & (h - 1);
+      const uint32_t i0 = (grp << (st + 2)) + pos;
+      Fr29 a = lds_get(s, i0), b = lds_get(s, i0 + h), c = lds_get(s, i0 + 2 * h), d = lds_get(s, i0 + 3 * h);
+      if (st == 0) {
+        butterfly29<true, false>(a, b, a, Fr29Params::K2);
+        butterfly29<true, false>(c, d, c, Fr29Params::K2);
+        butterfly29<true, true>(a, c, a, Fr29Params::K4);
+        const Fr29 w3 = w[N >> 2];
+        butterfly29<false, true>(b, d, w3, Fr29Params::K2);
+      } else {
+        const Fr29 w1 = w[pos << (logN - 1 - st)];
+        butterfly29<false, false>(a, b, w1, Fr29Params::K2);
+        butterfly29<false, false>(c, d, w1, Fr29Params::K2);
+        const Fr29 w2 = w[pos << (logN - 2 - st)];
+        butterfly29<false, true>(a, c, w2, Fr29Params::K2);
+        const Fr29 w3 = w[(pos + h) << (logN - 2 - st)];
+        butterfly29<false, true>(b, d, w3, Fr29Params::K2);
+      }
+      lds_put(s, i0, a);
+      lds_put(s, i0 + h, b);
+      lds_put(s, i0 + 2 * h, c);
+      lds_put(s, i0 + 3 * h, d);
+    }
+    __syncthreads();
+  }
+  if (st < logN) {  // odd number of stages: one radix-2 round
+    const uint32_t h = 1u << st;
+    for (uint32_t u = tid; u < (N >> 1); u += SMALL_THREADS) {
+      const uint32_t grp = u >> st, pos = u & (h - 1);
+      const uint32_t i0 = (grp << (st + 1)) + pos;
+      Fr29 a = lds_get(s, i0), b = lds_get(s, i0 + h);
+      const Fr29 w1 = w[pos << (logN - 1 - st)];
+      butterfly29<false, true>(a, b, w1, Fr29Params::K2);
+      lds_put(s, i0, a);
+      lds_put(s, i0 + h, b);
+    }
+    __syncthreads();
+  }
+}
+
+struct SmallChains {
+  const Fr* in[3];
+  Fr* out[3];
+};
+
+// Workgroup 0: a <- coset_fft(ifft(a)); workgroup 1: the same for b; workgroup 2: c <- ifft(c) / Z.
+// gm[i] = g^i / m, kz[0] = 1 / (m Z); w_inv / w_fwd: the domain's roots for the two directions.  1 <= logN.
+__global__ __launch_bounds__(SMALL_THREADS) void k_small_chains(SmallChains v, uint32_t logN,
+                                                                const Fr29* __restrict__ w_inv, const Fr29* __restrict__ w_fwd,
+                                                                const Fr29* __restrict__ gm, const Fr29* __restrict__ kz) {
+  __shared__ uint32_t s[(1u << SMALL_MAX_LOG) * 9];
+  const uint32_t which = blockIdx.x, N = 1u << logN, tid = threadIdx.x, rs = 32 - logN;
+  const Fr* in = v.in[which];
+  Fr* out = v.out[which];
+  for (uint32_t i = tid; i < N; i += SMALL_THREADS) lds_put(s, __brev(i) >> rs, unpack29<Fr29Params>(in[i]));
+  __syncthreads();
+  small_dit(s, logN, w_inv);
+  if (which == 2) {
+    const Fr29 f = kz[0];
+    for (uint32_t i = tid; i < N; i += SMALL_THREADS) out[i] = pack29<Fr29Params, FrParams>(mul(lds_get(s, i), f));
+    return;
+  }
+  // times g^i / m, and into bit-reversed position for the forward transform: positions i and brev(i) swap, so every
+  // lane works on its own pair and no barrier is needed inside the step
+  for (uint32_t i = tid; i < N; i += SMALL_THREADS) {
+    const uint32_t j = __brev(i) >> rs;
+    if (i < j) {
+      const Fr29 xi = mul(lds_get(s, i), gm[i]), xj = mul(lds_get(s, j), gm[j]);
+      lds_put(s, j, xi);
+      lds_put(s, i, xj);
+    } else if (i == j) {
+      lds_put(s, i, mul(lds_get(s, i), gm[i]));
+    }
+  }
+  __syncthreads();
+  small_dit(s, logN, w_fwd);
+  const Fr29 one = Fr29::one();
+  for (uint32_t i = tid; i < N; i += SMALL_THREADS) out[i] = pack29<Fr29Params, FrParams>(mul(lds_get(s, i), one));
+}
+
+// out <- icoset_fft(a * b) / Z - c for the coset evaluations a, b and c = ifft(c) / Z (out may be a).
+// hz[i] = 32 g^-i / (m Z): the product of two radix-2^256 values reduced by 2^261 is a * b / 32.
+__global__ __launch_bounds__(SMALL_THREADS) void k_small_finish(const Fr* a, const Fr* __restrict__ b, const Fr* __restrict__ c,
+                                                                Fr* out, uint32_t logN, const Fr29* __restrict__ w_inv,
+                                                                const Fr29* __restrict__ hz) {
+  __shared__ uint32_t s[(1u << SMALL_MAX_LOG) * 9];
+  const uint32_t N = 1u << logN, tid = threadIdx.x, rs = 32 - logN;
+  for (uint32_t i = tid; i < N; i += SMALL_THREADS)
+    lds_put(s, __brev(i) >> rs, mul(unpack29<Fr29Params>(a[i]), unpack29<Fr29Params>(b[i])));
+  __syncthreads();
+  small_dit(s, logN, w_inv);
+  for (uint32_t i = tid; i < N; i += SMALL_THREADS)
+    out[i] = sub(pack29<Fr29Params, FrParams>(mul(lds_get(s, i), hz[i])), c[i]);
+}
+
 // factor[o] = w^e for the inter-pass twiddle exponent e of every element a pass stores, in store order.
 __global__ __launch_bounds__(256) void k_pass_twiddles(PassParams p, const Fr29* __restrict__ w, Fr29* __restrict__ factor) {
   const uint32_t logR = p.logR, logT = p.logT;
@@ -364,7 +479,8 @@ static zg16_status get_domain(zg16_ctx* ctx, unsigned log_n, NttDomain** out) {
   }
   const size_t N = (size_t)1 << log_n;
   const size_t n_tw = (d->plan.r1 ? 2 : 0) + (d->plan.r2 ? 2 : 0);
-  const size_t bytes29 = ((3 + n_tw) * N + 2 * 512 + 8) * sizeof(Fr29), bytes = bytes29 + N * sizeof(Fr);
+  const size_t n_dom = log_n >= 1 && log_n <= SMALL_MAX_LOG ? N / 2 : 0;
+  const size_t bytes29 = ((3 + n_tw) * N + 2 * 512 + 8 + 2 * n_dom) * sizeof(Fr29), bytes = bytes29 + N * sizeof(Fr);
   // staging that is released again: the exponent-indexed power tables the store-order tables are built from
   const size_t stage_bytes = N * sizeof(Fr29) + (N + 512) * sizeof(Fr);
   void* stage = nullptr;
@@ -384,6 +500,7 @@ static zg16_status get_domain(zg16_ctx* ctx, unsigned log_n, NttDomain** out) {
   d->kz = p; p += 8;
   d->w_small[0] = p; p += 512;
   d->w_small[1] = p; p += 512;
+  if (n_dom) { d->w_dom[0] = p; p += n_dom; d->w_dom[1] = p; p += n_dom; }
   d->g = (Fr*)((char*)d->block + bytes29);
   Fr29* w_full = (Fr29*)stage;
   Fr* tmp = (Fr*)((char*)stage + N * sizeof(Fr29));
@@ -419,6 +536,10 @@ static zg16_status get_domain(zg16_ctx* ctx, unsigned log_n, NttDomain** out) {
   table29(d->kz, 1, one, kz);
   table29(d->w_small[0], 512, w1024, one);
   table29(d->w_small[1], 512, w1024_inv, one);
+  if (n_dom) {
+    table29(d->w_dom[0], n_dom, omega, one);
+    table29(d->w_dom[1], n_dom, omega_inv, one);
+  }
   launch(d->g, N, g, one);
   hipError_t le = hipGetLastError();
   hipError_t se = hipStreamSynchronize(st);
@@ -536,6 +657,22 @@ zg16_status h_pipeline_device(zg16_ctx* ctx, Fr* a, Fr* b, Fr* c, unsigned log_m
   }
   NttDomain* d;
   ZG_TRY(get_domain(ctx, log_m, &d));
+  // ZG16_SMALL_H=0 sends small domains through the general passes too (read per call: tests compare the two)
+  const char* small_knob = getenv("ZG16_SMALL_H");
+  if (d->w_dom[0] && !(small_knob && atoi(small_knob) == 0)) {
+    const double bytes = 64.0 * (double)((size_t)1 << log_m);
+    const SmallChains v = {{a, b, c}, {a, b, c}};
+    {
+      KernelTimer kt(ctx, K_NTT_PASS, 5 * bytes);
+      k_small_chains<<<3, SMALL_THREADS, 0, ctx->stream>>>(v, log_m, d->w_dom[1], d->w_dom[0], d->gm, d->kz);
+    }
+    {
+      KernelTimer kt(ctx, K_NTT_PASS, bytes);
+      k_small_finish<<<1, SMALL_THREADS, 0, ctx->stream>>>(a, b, c, a, log_m, d->w_dom[1], d->hz);
+    }
+    ZG_HIP(ctx, hipGetLastError());
+    return ZG16_OK;
+  }
   // c <- ifft(c) / Z
   const PassExtras scale_c = {d->kz, nullptr, nullptr, 1};
   ZG_TRY(ntt_raw(ctx, d, c, c, true, nullptr, &scale_c));

@@ -198,7 +198,9 @@ static zg16_status spmv_launch(zg16_ctx* ctx, const zg16_r1cs* r, int first, int
     max_long = m.n_long > max_long ? m.n_long : max_long;
     nnz += (double)m.nnz;
   }
-  const double share = r->n_rows ? (double)map.n_out / (double)(map.log_blk >= 31 ? r->n_rows : ((size_t)1 << r->log_m)) : 0.0;
+  // share of the matrices this launch evaluates (slots past the last row are padding: zeros, no terms)
+  const double rows_here = map.log_blk >= 31 && map.n_out > r->n_rows ? (double)r->n_rows : (double)map.n_out;
+  const double share = r->n_rows ? rows_here / (double)(map.log_blk >= 31 ? r->n_rows : ((size_t)1 << r->log_m)) : 0.0;
   KernelTimer kt(ctx, K_SPMV, share * (nnz * 36 + (double)count * r->n_rows * 36) + (double)count * (r->n_in + r->n_aux) * 32);
   if (map.n_out) k_spmv_short<<<dim3((map.n_out + 255) / 256, count), 256, 0, st>>>(batch, z, map);
   if (max_long) k_spmv_long<<<dim3((max_long + 3) / 4, count), 256, 0, st>>>(batch, z, map);
