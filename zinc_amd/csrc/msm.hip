@@ -49,6 +49,12 @@ static constexpr uint32_t KEY_MASK = 0x00ffffffu;  // level-0 keys carry the win
 // Minimum waves per SIMD requested from the register allocator for the curve kernels.
 template <class F>
 constexpr int kMinWaves = MsmOps<F>::MIN_WAVES;
+// The two launches of a direct-table multiexp (a small circuit's proof) are chains of dependent group additions on
+// few waves with nothing else on the GPU: compiled for two waves per SIMD (256 registers) they do not spill.  The
+// latency-bound kernels that END a bucket multiexp (k_combine, k_heavy, k_split_sums, k_sum_range) spill 40-144 bytes
+// per lane at the four-wave register cut too, but they run beside other pipelines' accumulations, and waves twice as
+// wide there take the registers of two accumulating waves: measured, a 2^20-row proof went from 4.2 to 4.45 ms.
+constexpr int kTailWaves = 2;
 
 template <class F>
 struct JobTable {
@@ -645,7 +651,7 @@ __global__ __launch_bounds__(256, kMinWaves<F>) void k_split_sums(const typename
 
 // out_std[w] = sum of part[w][0..count), in the library-wide XYZZ form.  One workgroup per w.
 template <class F>
-__global__ __launch_bounds__(256, kMinWaves<F>) void k_sum_partials(const typename MsmOps<F>::PtMem* __restrict__ part,
+__global__ __launch_bounds__(256, kTailWaves) void k_sum_partials(const typename MsmOps<F>::PtMem* __restrict__ part,
                                                                       uint32_t count, XYZZ<F>* __restrict__ out_std) {
   using O = MsmOps<F>;
   __shared__ typename O::Pt sh[128];
@@ -755,7 +761,7 @@ template zg16_status msm_build_direct<Fq2>(zg16_ctx*, const Affine<Fq2>*, size_t
 // Job blockIdx.y: every logical thread adds the looked-up multiples of a contiguous share of the job's
 // (window, term) pairs, the workgroup tree-adds, one partial per workgroup at part[job * gridDim.x + blockIdx.x].
 template <class F>
-__global__ __launch_bounds__(256, kMinWaves<F>) void k_direct_sum(JobTable<F> jt, DirectBias bias,
+__global__ __launch_bounds__(256, kTailWaves) void k_direct_sum(JobTable<F> jt, DirectBias bias,
                                                                     typename MsmOps<F>::PtMem* __restrict__ part,
                                                                     uint32_t* __restrict__ err_flag) {
   using O = MsmOps<F>;
