@@ -43,6 +43,45 @@ __global__ void k_add_full_chain(XYZZ<Fq>* out, const Affine<Fq>* pts261, int np
   out[t] = export_xyzz<Fq29Params, FqParams>(a);
 }
 
+
+// the shuffle fold of the bucket-fold kernels in isolation: every lane starts from one point, `levels` levels of
+// shuffle + full addition under `if (lane < d)`.  mode 0: as the kernels do it; 1: the shuffles only; 2: the additions
+// only (the other operand stays in the lane); 3: the addition for every lane (no branch)
+__global__ void k_fold(XYZZ<Fq>* out, const Affine<Fq>* pts261, int npts, int levels, int mode) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, lt = threadIdx.x & 63;
+  G1XYZZ29 acc = G1XYZZ29::inf(), other = G1XYZZ29::inf();
+  add_mixed29(acc, unpack_affine<Fq29Params>(pts261[t % npts]));
+  add_mixed29(other, unpack_affine<Fq29Params>(pts261[(t * 7 + 3) % npts]));
+#pragma unroll 1
+  for (int d = 1 << (levels - 1); d >= 1; d >>= 1) {
+    G1XYZZ29 o = other;
+    if (mode != 2) {
+      const uint32_t* src = (const uint32_t*)&acc;
+      uint32_t* dst = (uint32_t*)&o;
+#pragma unroll
+      for (int i = 0; i < (int)(sizeof(G1XYZZ29) / 4); i++) dst[i] = __shfl_down(src[i], d);
+    }
+    if (mode == 1) {
+      acc.x.v[0] ^= o.x.v[0] & 1;
+    } else if (mode == 3) {
+      add_full29(acc, other);
+      acc.x.v[0] ^= o.x.v[0] & 0;
+    } else if (mode == 4) {   // every lane adds; lanes outside the fold add the identity
+      if (lt >= d) o = G1XYZZ29::inf();
+      add_full29(acc, o);
+    } else if (mode == 5) {   // every lane adds what the shuffle gave it (its own point at the wave's end: a doubling)
+      add_full29(acc, o);
+    } else if (mode == 6) {   // lanes outside the fold add into a scratch copy
+      G1XYZZ29 tmp = acc;
+      add_full29(tmp, lt < d ? o : other);
+      if (lt < d) acc = tmp;
+    } else if (lt < d) {
+      add_full29(acc, o);
+    }
+  }
+  out[t] = export_xyzz<Fq29Params, FqParams>(acc);
+}
+
 __global__ void k_madd_chain(XYZZ<Fq>* acc, const Affine<Fq>* pts, int npts, int iters) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   XYZZ<Fq> a = XYZZ<Fq>::inf();
@@ -159,6 +198,11 @@ int main() {
     printf("lone wave, dependent full additions (hot code): %.2f us each\n", ms * 1e3 / 200);
     ms = time_kernel([&] { k_add_full_chain<<<1, 64>>>(d1, dp261, npts, 1); });
     printf("lone wave, kernel with ONE full addition + 3 mixed: %.2f us\n", ms * 1e3);
+    for (int mode = 0; mode < 7; mode++)
+      for (int levels : {4, 6}) {
+        ms = time_kernel([&] { k_fold<<<16, 256>>>(d1, dp261, npts, levels, mode); });
+        printf("fold: 64 waves, mode %d, %d levels: %.2f us\n", mode, levels, ms * 1e3);
+      }
   }
   printf("done\n");
   return 0;

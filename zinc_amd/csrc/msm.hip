@@ -565,7 +565,18 @@ ZG_D void block_sum(typename MsmOps<F>::Pt& total, typename MsmOps<F>::Pt* sh /*
   for (uint32_t stride = 128; stride >= (uint32_t)O::LP; stride >>= 1) {
     if (tid >= stride && tid < 2 * stride) sh[tid - stride] = total;
     __syncthreads();
-    if (tid < stride) O::add(total, sh[tid]);
+    if (stride >= 64) {
+      if (tid < stride) O::add(total, sh[tid]);  // whole waves add or sit out
+    } else if (tid < 64) {
+      // the levels inside the first wave: every lane runs the addition, the lanes outside the tree repeat logical
+      // thread 0's and drop the result (a wave that runs a group addition with part of its lanes switched off
+      // takes several times longer over it -- see k_split_sums)
+      const bool in_tree = tid < stride;
+      const typename O::Pt total0 = O::first_thread(total);
+      typename O::Pt x = in_tree ? total : total0;
+      O::add(x, sh[in_tree ? tid : tid % O::LP]);
+      if (in_tree) total = x;
+    }
     __syncthreads();
   }
 }
@@ -635,10 +646,19 @@ __global__ __launch_bounds__(256, kMinWaves<F>) void k_split_sums(const typename
   // the fold starts at the first level that still has a point in its upper half (r and h are powers of two): a
   // second-level array of 16 points would otherwise spend two of its six dependent additions on identities
   const uint32_t count = task < r ? h : r;
+  // Every lane of the wave runs every addition: the lanes outside the fold repeat logical thread 0's (and drop the
+  // result).  Measured: with the addition under `if (lt < d)` a fold of four levels took 110 us, with every lane
+  // adding 50-65 us -- a wave whose lanes leave the addition at different points runs it several times slower than
+  // one that goes through it whole.
 #pragma unroll 1
   for (uint32_t d = (count < LT ? count : LT) / 2; d >= 1; d >>= 1) {
     const typename O::Pt o = O::shfl_down(acc, d * O::LP);
-    if (lt < d) O::add(acc, o);
+    const bool in_fold = lt < d;
+    const typename O::Pt acc0 = O::first_thread(acc), o0 = O::first_thread(o);  // (shuffles: every lane takes part)
+    typename O::Pt x = in_fold ? acc : acc0;
+    const typename O::Pt y = in_fold ? o : o0;
+    O::add(x, y);
+    if (in_fold) acc = x;
   }
   if (lt == 0) {
     const size_t dst = (size_t)set * ss.out_stride + ss.out_off[a] + task;

@@ -52,6 +52,15 @@ struct MsmOps<Fq> {
     for (int i = 0; i < (int)(sizeof(Pt) / 4); i++) dst[i] = __shfl_down(src[i], d);
     return o;
   }
+  // logical thread 0's copy of p, in every lane of the wave
+  ZG_D static Pt first_thread(const Pt& p) {
+    Pt o;
+    const uint32_t* src = (const uint32_t*)&p;
+    uint32_t* dst = (uint32_t*)&o;
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(Pt) / 4); i++) dst[i] = __shfl(src[i], 0);
+    return o;
+  }
   // the library-wide XYZZ form (radix-2^256 Montgomery, canonical) for the host
   ZG_D static void store_std(XYZZ<Fq>* dst, const Pt& p) { *dst = export_xyzz<Fq29Params, FqParams>(p); }
   // ABI form -> internal packed form
@@ -101,6 +110,14 @@ struct MsmOps<Fq2> {
     uint32_t* dst = (uint32_t*)&o;
 #pragma unroll
     for (int i = 0; i < (int)(sizeof(Pt) / 4); i++) dst[i] = __shfl_down(src[i], d);
+    return o;
+  }
+  ZG_D static Pt first_thread(const Pt& p) {  // lanes 0 and 1 hold logical thread 0's two components
+    Pt o;
+    const uint32_t* src = (const uint32_t*)&p;
+    uint32_t* dst = (uint32_t*)&o;
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(Pt) / 4); i++) dst[i] = __shfl(src[i], (int)sub());
     return o;
   }
   ZG_D static void store_std(XYZZ<Fq2>* dst, const Pt& p) {
