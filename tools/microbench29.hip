@@ -82,6 +82,18 @@ __global__ void k_fold(XYZZ<Fq>* out, const Affine<Fq>* pts261, int npts, int le
   out[t] = export_xyzz<Fq29Params, FqParams>(acc);
 }
 
+// a lone wave running dependent full additions with only the first `active` lanes switched on
+__global__ void k_add_active(XYZZ<Fq>* out, const Affine<Fq>* pts261, int npts, int iters, int active) {
+  const int t = threadIdx.x;
+  G1XYZZ29 a = G1XYZZ29::inf(), b = G1XYZZ29::inf();
+  add_mixed29(a, unpack_affine<Fq29Params>(pts261[t % npts]));
+  add_mixed29(b, unpack_affine<Fq29Params>(pts261[(t + 7) % npts]));
+  add_mixed29(b, unpack_affine<Fq29Params>(pts261[(t + 9) % npts]));
+  if (t < active)
+    for (int i = 0; i < iters; i++) add_full29(a, b);
+  out[t] = export_xyzz<Fq29Params, FqParams>(a);
+}
+
 __global__ void k_madd_chain(XYZZ<Fq>* acc, const Affine<Fq>* pts, int npts, int iters) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   XYZZ<Fq> a = XYZZ<Fq>::inf();
@@ -198,6 +210,15 @@ int main() {
     printf("lone wave, dependent full additions (hot code): %.2f us each\n", ms * 1e3 / 200);
     ms = time_kernel([&] { k_add_full_chain<<<1, 64>>>(d1, dp261, npts, 1); });
     printf("lone wave, kernel with ONE full addition + 3 mixed: %.2f us\n", ms * 1e3);
+    for (int active : {64, 48, 32, 17, 16, 8, 4, 1}) {
+      ms = time_kernel([&] { k_add_active<<<1, 64>>>(d1, dp261, npts, 200, active); });
+      printf("lone wave, %2d lanes switched on: %.2f us per dependent full addition\n", active, ms * 1e3 / 200);
+    }
+    for (int active : {64, 8})
+      for (int it : {1, 2, 4, 8}) {
+        ms = time_kernel([&] { k_add_active<<<16, 256>>>(d1, dp261, npts, it, active); });
+        printf("64 waves, %2d of every 256 threads switched on, %d additions: %.2f us\n", active, it, ms * 1e3);
+      }
     for (int mode = 0; mode < 7; mode++)
       for (int levels : {4, 6}) {
         ms = time_kernel([&] { k_fold<<<16, 256>>>(d1, dp261, npts, levels, mode); });
