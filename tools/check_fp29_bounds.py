@@ -1,4 +1,4 @@
-"""Worst-case bound check of the lazy 29-bit-limb arithmetic in zinc_amd/csrc/{fp29,curve29}.cuh.
+"""Worst-case bound check of the lazy 29-bit-limb arithmetic in zinc_amd/csrc/{fp29,curve29}.hpp.
 
 Every field value is tracked as (v, L): v = upper bound of the value in units of p, L = upper bound
 of a limb below the top one.  The operations mirror the device code one to one and assert

@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <vector>
-#include "curve29.cuh"
+#include "curve29.hpp"
 using namespace zg;
 
 template <int V>

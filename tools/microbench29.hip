@@ -5,7 +5,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
-#include "curve29.cuh"
+#include "curve29.hpp"
 
 using namespace zg;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)

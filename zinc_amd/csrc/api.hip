@@ -12,7 +12,7 @@
 #include <chrono>
 #include <memory>
 
-#include "r1cs.cuh"
+#include "r1cs.hpp"
 
 using namespace zg;
 

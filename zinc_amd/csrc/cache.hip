@@ -13,7 +13,7 @@
 #include <algorithm>
 #include <mutex>
 
-#include "r1cs.cuh"
+#include "r1cs.hpp"
 
 namespace zg {
 

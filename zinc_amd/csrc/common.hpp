@@ -9,7 +9,7 @@
 #include <vector>
 
 #include "../../include/zinc_groth16.h"
-#include "curve.cuh"
+#include "curve.hpp"
 
 namespace zg {
 

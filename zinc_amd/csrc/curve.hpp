@@ -10,10 +10,10 @@
 // point bellman_ce's Jacobian code produces (the reference calls it through
 // zinc-vm/src/core/circuit/facade.rs:153).
 #pragma once
-#include "field.cuh"
+#include "field.hpp"
 
 // Group operations are inlined into their callers; the field product underneath may be out of line
-// (see ZG_OUTLINE_FIELD_MUL in field.cuh).
+// (see ZG_OUTLINE_FIELD_MUL in field.hpp).
 #define ZG_GROUP_OP ZG_HD
 
 namespace zg {

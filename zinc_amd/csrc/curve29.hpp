@@ -1,6 +1,6 @@
-// BN254 G1 group operations over the 29-bit-limb field of fp29.cuh (device only).
+// BN254 G1 group operations over the 29-bit-limb field of fp29.hpp (device only).
 //
-// Same formulas as curve.cuh (extended Jacobian XYZZ: madd-2008-s, add-2008-s, dbl-2008-s-1), with
+// Same formulas as curve.hpp (extended Jacobian XYZZ: madd-2008-s, add-2008-s, dbl-2008-s-1), with
 // the value bounds of the lazy field written next to each step in units of p:
 //   stored points:  X < 8p,  Y < 5p,  ZZ, ZZZ < 2p,  limbs normalised;  ZZ == 0 (all limbs) <=> identity
 //   affine bases:   x, y < p canonical
@@ -8,8 +8,8 @@
 // Exact group results do not depend on any of this: the affine point is the one bellman_ce computes
 // (reached from zinc-vm/src/core/circuit/facade.rs:153).
 #pragma once
-#include "curve.cuh"
-#include "fp29.cuh"
+#include "curve.hpp"
+#include "fp29.hpp"
 
 namespace zg {
 

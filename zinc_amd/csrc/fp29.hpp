@@ -3,7 +3,7 @@
 //
 // Why.  The widest integer multiply of CDNA4 is v_mad_u64_u32 (32 x 32 + 64 -> 64) and it has no
 // carry input, so with saturated 32-bit limbs every product term needs a second instruction to
-// propagate its carry (field.cuh's device product: 128 multiply-adds + 128 carry adds + moves).
+// propagate its carry (field.hpp's device product: 128 multiply-adds + 128 carry adds + moves).
 // With 29-bit limbs a whole column of the product scan -- nine a_i*b_j terms and nine m_i*p_j
 // terms, each below 2^58 -- accumulates in one 64-bit register with no carry at all, so a term is
 // exactly one instruction: 162 multiply-adds and ~60 shifts / masks per Montgomery product.  The
@@ -21,7 +21,7 @@
 // canonical form (in radix-2^261 Montgomery form, see to_r261); accumulators are stored as nine
 // limbs per coordinate.
 #pragma once
-#include "field.cuh"
+#include "field.hpp"
 
 namespace zg {
 

@@ -17,7 +17,7 @@
 #include <memory>
 
 #define ZG_OUTLINE_FIELD_MUL 1
-#include "r1cs.cuh"
+#include "r1cs.hpp"
 
 namespace zg {
 

@@ -35,8 +35,8 @@
 
 #include <algorithm>
 
-#include "r1cs.cuh"
-#include "msm_ops.cuh"
+#include "r1cs.hpp"
+#include "msm_ops.hpp"
 
 namespace zg {
 

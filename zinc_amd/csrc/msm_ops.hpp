@@ -8,14 +8,14 @@
 //
 // Bases are read from the "internal packed" form the key tables are stored in (to_internal).
 #pragma once
-#include "curve29.cuh"
+#include "curve29.hpp"
 
 namespace zg {
 
 template <class F>
 struct MsmOps;
 
-// G1: 29-bit-limb field (fp29.cuh), one lane per point.  Packed bases are in radix-2^261
+// G1: 29-bit-limb field (fp29.hpp), one lane per point.  Packed bases are in radix-2^261
 // Montgomery form, i.e. the ABI's radix-2^256 value times 32.
 template <>
 struct MsmOps<Fq> {

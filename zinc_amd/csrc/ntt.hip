@@ -11,8 +11,8 @@
 // pass C transforms over i3 (contiguous) for a tile of adjacent k1 and scatters to natural order.
 // Each workgroup stages a T x R tile (T*R <= 1024 elements, 32 KiB) in LDS and runs the R-point
 // transforms there, so every pass is one read and one write of the array.
-#include "common.cuh"
-#include "fp29.cuh"
+#include "common.hpp"
+#include "fp29.hpp"
 
 namespace zg {
 

@@ -4,7 +4,7 @@
 #include <memory>
 #include <thread>
 
-#include "common.cuh"
+#include "common.hpp"
 
 namespace zg {
 

@@ -3,8 +3,8 @@
 #include <string.h>
 
 #define ZG_OUTLINE_FIELD_MUL 1
-#include "common.cuh"
-#include "msm_ops.cuh"
+#include "common.hpp"
+#include "msm_ops.hpp"
 
 namespace zg {
 

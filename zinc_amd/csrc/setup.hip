@@ -12,7 +12,7 @@
 #include <vector>
 
 #define ZG_OUTLINE_FIELD_MUL 1
-#include "r1cs.cuh"
+#include "r1cs.hpp"
 
 namespace zg {
 

@@ -26,7 +26,7 @@
 #include <mutex>
 #include <thread>
 
-#include "r1cs.cuh"
+#include "r1cs.hpp"
 
 using namespace zg;
 

@@ -17,7 +17,7 @@
 
 #include <unordered_map>
 
-#include "r1cs.cuh"
+#include "r1cs.hpp"
 
 namespace zg {
 

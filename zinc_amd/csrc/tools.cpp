@@ -17,7 +17,7 @@
 #include <algorithm>
 #include <vector>
 
-#include "field.cuh"
+#include "field.hpp"
 
 using namespace zg;
 

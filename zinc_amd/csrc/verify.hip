@@ -16,7 +16,7 @@
 // Tower: Fq2 = Fq[u] / (u^2 + 1), Fq6 = Fq2[v] / (v^3 - xi) with xi = 9 + u, Fq12 = Fq6[w] / (w^2 - v).
 #include <string.h>
 
-#include "curve.cuh"
+#include "curve.hpp"
 #include "../../include/zinc_groth16.h"
 
 namespace zg {
