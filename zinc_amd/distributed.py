@@ -130,8 +130,8 @@ def run_sharded_stages(stage, work, got, world, device=None, after_exchange=None
     for k in range(4):
         n = stage(k)
         for v in range(n):
-            # (with gloo the exchange is staged through the host and lands back in the source tensor)
-            got[v].copy_(_all_to_all(work[v], world, device))
+            # straight into the receiving buffer (with gloo the exchange is staged through the host)
+            _all_to_all(work[v], world, device, out=got[v])
         if n and after_exchange is not None:
             after_exchange()
 
@@ -205,15 +205,16 @@ def ntt_shard_output_index(n, rank, world):
     return (rank * blk + i + length * k1).reshape(-1)
 
 
-def _all_to_all(t, world, device):
+def _all_to_all(t, world, device, out=None):
     """Equal-split all-to-all of a (L, 4) int64 tensor: chunk h goes to rank h, which stores what it
     gets from rank g at chunk g.  RCCL moves device memory; with gloo (CPU rehearsal) the data is staged
-    through the host."""
+    through the host.  out: a tensor of the same shape to receive into (a different one from t); without it the
+    result is a new tensor (RCCL) or t itself (gloo)."""
     import torch
     import torch.distributed as dist
     staged = dist.get_backend() == "gloo"
     src = t.cpu() if staged else t
-    dst = torch.empty_like(src)
+    dst = out if out is not None and not staged else torch.empty_like(src)
     try:
         dist.all_to_all_single(dst, src)
     except RuntimeError:
@@ -229,8 +230,9 @@ def _all_to_all(t, world, device):
         for r in reqs:
             r.wait()
     if staged:
-        t.copy_(dst)
-        return t
+        res = t if out is None else out
+        res.copy_(dst)
+        return res
     # RCCL's wait() orders only torch's current stream; the library works on its own streams
     torch.cuda.current_stream(device).synchronize()
     return dst
