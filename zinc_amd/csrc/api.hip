@@ -388,6 +388,10 @@ zg16_status zg16_r1cs_upload(zg16_ctx* ctx, const zg16_r1cs_view* v, zg16_r1cs**
       ZG_TRY(dev_alloc_copy(ctx, &d.code, codes.data(), nnz));
       ZG_TRY(dev_alloc_copy(ctx, &d.table, table.data(), table.size()));
       if (needs_full) ZG_TRY(dev_alloc_copy(ctx, &d.coeff, m.coeff, nnz));
+      std::vector<uint32_t> order;
+      spmv_row_order(rp.data(), v->n_rows, codes.data(), order);
+      d.n_order = (uint32_t)order.size();
+      ZG_TRY(dev_alloc_copy(ctx, &d.order, order.data(), order.size()));
     }
     ZG_TRY(dev_alloc_copy(ctx, &d.long_rows, longs.data(), longs.size()));
   }
@@ -423,7 +427,7 @@ void zg::r1cs_destroy(zg16_r1cs* r) {
   }
   for (auto& m : r->m) {
     (void)hipFree(m.row_ptr); (void)hipFree(m.col); (void)hipFree(m.coeff); (void)hipFree(m.long_rows);
-    (void)hipFree(m.code); (void)hipFree(m.table);
+    (void)hipFree(m.code); (void)hipFree(m.table); (void)hipFree(m.order);
   }
   (void)hipFree(r->a_map); (void)hipFree(r->b_map);
   delete r;

@@ -23,6 +23,11 @@ struct R1csMatrix {
   Fr* coeff = nullptr;          // full coefficients; only kept when the matrix has more distinct values than codes
   uint32_t* long_rows = nullptr;
   uint32_t n_long = 0;
+  // The short rows ordered by (term count, any coefficient other than +-1), row index increasing inside a class:
+  // consecutive lanes then run the same number of term rounds down the same path (spmv_row_order).  Null when the
+  // matrix was built without it (the launch then takes the rows in their own order).
+  uint32_t* order = nullptr;
+  uint32_t n_order = 0;
   size_t nnz = 0;
 };
 
@@ -46,6 +51,8 @@ zg16_status spmv_one_device(zg16_ctx* ctx, const zg16_r1cs* r, int k, const Fr* 
 // rows (j >> log_blk) * stride + base + (j mod 2^log_blk) for j < n_out (padding rows give zero)
 zg16_status spmv_blocks_device(zg16_ctx* ctx, const zg16_r1cs* r, const Fr* z, Fr* a, Fr* b, Fr* c, uint32_t log_blk,
                                uint32_t stride, uint32_t base, uint32_t n_out);
+// The short rows (at most SPMV_LONG_ROW terms) of a CSR matrix sorted by class; codes are spmv_encode_coeffs'.
+void spmv_row_order(const uint32_t* row_ptr, size_t n_rows, const uint16_t* codes, std::vector<uint32_t>& order);
 void spmv_encode_coeffs(const uint64_t* coeff, size_t nnz, std::vector<uint16_t>& codes, std::vector<Fr>& table,
                         bool* needs_full);
 

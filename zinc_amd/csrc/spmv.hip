@@ -104,6 +104,35 @@ void spmv_encode_coeffs(const uint64_t* coeff, size_t nnz, std::vector<uint16_t>
   }
 }
 
+// Rows of one shape are scattered all over a circuit (a boolean row here, an eight-term linear combination there),
+// and a wavefront that takes 64 consecutive rows runs as many term rounds as its longest row and the product path
+// if any of its rows needs it.  Ordered by (term count, needs a product), 64 consecutive entries are 64 rows of
+// the same cost.  Counting sort, stable, so row indices rise inside a class and neighbouring lanes still touch
+// neighbouring rows wherever a circuit has runs of one shape.
+void spmv_row_order(const uint32_t* row_ptr, size_t n_rows, const uint16_t* codes, std::vector<uint32_t>& order) {
+  constexpr uint32_t NKEY = 2 * (SPMV_LONG_ROW + 1);
+  std::vector<uint8_t> key(n_rows);
+  host_parallel(n_rows, [&](size_t lo, size_t hi) {
+    for (size_t r = lo; r < hi; r++) {
+      const uint32_t len = row_ptr[r + 1] - row_ptr[r];
+      if (len > SPMV_LONG_ROW) {
+        key[r] = 0xff;
+        continue;
+      }
+      uint32_t product = 0;
+      for (uint32_t e = row_ptr[r]; e < row_ptr[r + 1]; e++) product |= codes[e] > 1 ? 1u : 0u;
+      key[r] = (uint8_t)(2 * len + product);
+    }
+  });
+  size_t start[NKEY + 1] = {};
+  for (size_t r = 0; r < n_rows; r++)
+    if (key[r] != 0xff) start[key[r] + 1]++;
+  for (uint32_t k = 0; k < NKEY; k++) start[k + 1] += start[k];
+  order.resize(start[NKEY]);
+  for (size_t r = 0; r < n_rows; r++)
+    if (key[r] != 0xff) order[start[key[r]]++] = (uint32_t)r;
+}
+
 // ---- kernels ------------------------------------------------------------------------------------------
 struct SpmvMatrix {
   const uint32_t* row_ptr;
@@ -147,6 +176,8 @@ struct SpmvBatch {
   Fr* out[3];
   const uint32_t* long_rows[3];
   uint32_t n_long[3];
+  const uint32_t* order[3];  // k_spmv_ordered: the short rows by class
+  uint32_t n_order[3];
 };
 
 __global__ __launch_bounds__(256) void k_spmv_short(SpmvBatch batch, const Fr* __restrict__ z, RowMap map) {
@@ -161,6 +192,25 @@ __global__ __launch_bounds__(256) void k_spmv_short(SpmvBatch batch, const Fr* _
     for (uint32_t e = lo; e < hi; e++) acc = add_term(acc, m, e, z);
   }
   batch.out[blockIdx.y][j] = acc;
+}
+
+// Every row in order (the whole matrix, no row map): lane j takes the j-th short row of the class order; the lanes
+// behind the last one write the zero padding [n_rows, n_out).  Long rows are left to k_spmv_long.
+__global__ __launch_bounds__(256) void k_spmv_ordered(SpmvBatch batch, const Fr* __restrict__ z, uint32_t n_rows,
+                                                      uint32_t n_out) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  const SpmvMatrix& m = batch.m[blockIdx.y];
+  const uint32_t n_order = batch.n_order[blockIdx.y];
+  if (j >= n_order) {
+    const uint32_t pad = n_rows + (j - n_order);
+    if (pad < n_out) batch.out[blockIdx.y][pad] = Fr::zero();
+    return;
+  }
+  const uint32_t r = batch.order[blockIdx.y][j];
+  const uint32_t lo = m.row_ptr[r], hi = m.row_ptr[r + 1];
+  Fr acc = Fr::zero();
+  for (uint32_t e = lo; e < hi; e++) acc = add_term(acc, m, e, z);
+  batch.out[blockIdx.y][r] = acc;
 }
 
 __global__ __launch_bounds__(256) void k_spmv_long(SpmvBatch batch, const Fr* __restrict__ z, RowMap map) {
@@ -187,22 +237,33 @@ static zg16_status spmv_launch(zg16_ctx* ctx, const zg16_r1cs* r, int first, int
                                const RowMap& map) {
   hipStream_t st = ctx->stream;
   SpmvBatch batch = {};
-  uint32_t max_long = 0;
+  uint32_t max_long = 0, max_order = 0;
   double nnz = 0;
+  // the class order covers whole matrices: launches over every row (and the padding behind them) use it
+  bool ordered = map.log_blk >= 31 && map.base == 0 && map.n_out >= r->n_rows && map.n_rows == r->n_rows;
   for (int k = 0; k < count; k++) {
     const R1csMatrix& m = r->m[first + k];
     batch.m[k] = {m.row_ptr, m.col, m.code, m.table, m.coeff};
     batch.out[k] = outs[k];
     batch.long_rows[k] = m.long_rows;
     batch.n_long[k] = m.n_long;
+    batch.order[k] = m.order;
+    batch.n_order[k] = m.n_order;
+    ordered = ordered && (m.order || !m.n_order) && (size_t)m.n_order + m.n_long == r->n_rows;
     max_long = m.n_long > max_long ? m.n_long : max_long;
+    max_order = m.n_order > max_order ? m.n_order : max_order;
     nnz += (double)m.nnz;
   }
   // share of the matrices this launch evaluates (slots past the last row are padding: zeros, no terms)
   const double rows_here = map.log_blk >= 31 && map.n_out > r->n_rows ? (double)r->n_rows : (double)map.n_out;
   const double share = r->n_rows ? rows_here / (double)(map.log_blk >= 31 ? r->n_rows : ((size_t)1 << r->log_m)) : 0.0;
   KernelTimer kt(ctx, K_SPMV, share * (nnz * 36 + (double)count * r->n_rows * 36) + (double)count * (r->n_in + r->n_aux) * 32);
-  if (map.n_out) k_spmv_short<<<dim3((map.n_out + 255) / 256, count), 256, 0, st>>>(batch, z, map);
+  if (ordered) {
+    const size_t lanes = (size_t)max_order + (map.n_out - r->n_rows);
+    if (lanes) k_spmv_ordered<<<dim3((unsigned)((lanes + 255) / 256), count), 256, 0, st>>>(batch, z, map.n_rows, map.n_out);
+  } else if (map.n_out) {
+    k_spmv_short<<<dim3((map.n_out + 255) / 256, count), 256, 0, st>>>(batch, z, map);
+  }
   if (max_long) k_spmv_long<<<dim3((max_long + 3) / 4, count), 256, 0, st>>>(batch, z, map);
   ZG_HIP(ctx, hipGetLastError());
   return ZG16_OK;
