@@ -8,7 +8,7 @@
 //
 // Two bucket layouts:
 //  * shared buckets (proving-key queries): the key holds 2^(c*w) * P for every window w
-//    (built once at upload by k_build_table -- 288 GB of HBM makes the W-fold copy cheap), so a
+//    (built once at upload by k_table_windows / k_table_affine -- 288 GB of HBM makes the W-fold copy cheap), so a
 //    digit d of window w is simply "add table[w][i] to bucket |d|".  All W windows share ONE set of
 //    2^(c-1) buckets: the bucket reduction shrinks W-fold and there is no window recombination.
 //  * per-window buckets (stand-alone multiexp on caller-supplied bases): W bucket sets, host Horner.
@@ -828,17 +828,65 @@ __global__ __launch_bounds__(256, kTailWaves) void k_direct_sum(JobTable<F> jt, 
 // table[w*stride + i] = 2^(c*w) * table[i] for w in 1..W-1, every window in the internal packed form
 // (window 0 arrives in the ABI form and is rewritten).  W = 1 just converts the points.  (c here is the distance
 // between two stored windows in bits: the digit width times the table step.)
+//
+// Bringing a window back to affine form is a field inversion -- three times the cost of the c doublings that lead
+// to it -- so it is not done per window.  Three kernels:
+//   k_table_convert   window 0 into the packed form the multiexp kernels read;
+//   k_table_windows   one logical thread per point (a lane pair for G2) runs the doublings in the 29-bit-limb
+//                     arithmetic of the multiexp kernels and leaves every window in XYZZ form in a scratch block
+//                     (window-major, so neighbouring threads store neighbouring slots);
+//   k_table_affine    per point: the running product of the windows' denominators ZZ*ZZZ, ONE inversion, and a
+//                     walk back from the last window that peels the single inverses off it (Montgomery's trick):
+//                     an inversion and ten products per point and window became thirteen products.
+// The coordinates are canonical field values, so the table does not depend on how they were reached.
+// Thread j of a launch handles point first + j; xyzz and prefix hold (W - 1) * chunk slots.
 template <class F>
-__global__ __launch_bounds__(256, 1) void k_build_table(Affine<F>* __restrict__ table, uint32_t n, uint32_t stride,
-                                                        uint32_t W, uint32_t c) {
+__global__ __launch_bounds__(256) void k_table_convert(Affine<F>* __restrict__ table, uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const Affine<F> p0 = table[i];
-  table[i] = MsmOps<F>::to_internal(p0);
-  XYZZ<F> acc = XYZZ<F>::from_affine(p0);
+  if (i < n) table[i] = MsmOps<F>::to_internal(table[i]);
+}
+
+template <class F>
+__global__ __launch_bounds__(256, kMinWaves<F>) void k_table_windows(const Affine<F>* __restrict__ table, uint32_t n,
+                                                                     uint32_t W, uint32_t c, uint32_t first, uint32_t chunk,
+                                                                     XYZZ<F>* __restrict__ xyzz) {
+  using Ops = MsmOps<F>;
+  const uint32_t j = (blockIdx.x * blockDim.x + threadIdx.x) / Ops::LP, i = first + j;
+  if (j >= chunk || i >= n) return;  // (the lanes of a pair share j)
+  typename Ops::Aff base;
+  typename Ops::Pt acc = Ops::inf();
+  if (Ops::load_base(table + i, false, &base)) Ops::madd(acc, base);
   for (uint32_t w = 1; w < W; w++) {
-    for (uint32_t k = 0; k < c; k++) acc = dbl(acc);
-    table[(size_t)w * stride + i] = MsmOps<F>::to_internal(to_affine(acc));
+    for (uint32_t k = 0; k < c; k++) acc = Ops::dbl(acc);
+    Ops::store_std(xyzz + (size_t)(w - 1) * chunk + j, acc);
+  }
+}
+
+template <class F>
+__global__ __launch_bounds__(256, 1) void k_table_affine(Affine<F>* __restrict__ table, uint32_t n, uint32_t stride,
+                                                         uint32_t W, uint32_t first, uint32_t chunk,
+                                                         const XYZZ<F>* __restrict__ xyzz, F* __restrict__ prefix) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x, i = first + j;
+  if (j >= chunk || i >= n) return;
+  F run = F::one();
+  for (uint32_t w = 1; w < W; w++) {
+    const XYZZ<F> a = xyzz[(size_t)(w - 1) * chunk + j];
+    // (a point of the prime-order group never doubles to the identity; a stray point that does is kept out of
+    // the product and stored as the identity below)
+    if (!a.is_inf()) run = mul(run, mul(a.zz, a.zzz));
+    prefix[(size_t)(w - 1) * chunk + j] = run;
+  }
+  F inv_run = inv(run);  // 1 / (t_1 ... t_(W-1)), t_w = ZZ_w * ZZZ_w
+  for (uint32_t w = W - 1; w >= 1; w--) {
+    const XYZZ<F> a = xyzz[(size_t)(w - 1) * chunk + j];
+    Affine<F> out = Affine<F>::inf();
+    if (!a.is_inf()) {
+      const F before = w > 1 ? prefix[(size_t)(w - 2) * chunk + j] : F::one();
+      const F it = mul(inv_run, before);         // 1 / t_w
+      inv_run = mul(inv_run, mul(a.zz, a.zzz));  // 1 / (t_1 ... t_(w-1))
+      out = {mul(a.x, mul(it, a.zzz)), mul(a.y, mul(it, a.zz))};
+    }
+    table[(size_t)w * stride + i] = MsmOps<F>::to_internal(out);
   }
 }
 
@@ -917,10 +965,35 @@ uint32_t msm_table_step(const TableQuery* q, int count) {
 template <class F>
 zg16_status msm_build_table(zg16_ctx* ctx, Affine<F>* table, size_t n, uint32_t c, uint32_t step) {
   if (!n) return ZG16_OK;
-  k_build_table<F><<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(table, (uint32_t)n, (uint32_t)n,
-                                                                        c ? msm_table_windows(c, step) : 1, c * step);
-  ZG_HIP(ctx, hipGetLastError());
-  ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const uint32_t W = c ? msm_table_windows(c, step) : 1;
+  // points per launch: the scratch block of a launch (W - 1 windows in XYZZ form and their prefix products) stays
+  // below about 1 GiB; freed again before returning -- a key upload is no place to keep it
+  size_t chunk = (size_t)1 << 18;
+  if (chunk > n) chunk = n;
+  XYZZ<F>* xyzz = nullptr;
+  F* prefix = nullptr;
+  if (W > 1) {
+    ZG_HIP(ctx, hipMalloc((void**)&xyzz, (size_t)(W - 1) * chunk * sizeof(XYZZ<F>)));
+    const hipError_t e = hipMalloc((void**)&prefix, (size_t)(W - 1) * chunk * sizeof(F));
+    if (e != hipSuccess) {
+      (void)hipFree(xyzz);
+      ZG_HIP(ctx, e);
+    }
+  }
+  hipStream_t st = ctx->stream;
+  k_table_convert<F><<<(unsigned)((n + 255) / 256), 256, 0, st>>>(table, (uint32_t)n);
+  for (size_t first = 0; W > 1 && first < n; first += chunk) {
+    const size_t here = n - first < chunk ? n - first : chunk;
+    k_table_windows<F><<<(unsigned)((here * MsmOps<F>::LP + 255) / 256), 256, 0, st>>>(table, (uint32_t)n, W, c * step, (uint32_t)first,
+                                                                                 (uint32_t)chunk, xyzz);
+    k_table_affine<F><<<(unsigned)((here + 255) / 256), 256, 0, st>>>(table, (uint32_t)n, (uint32_t)n, W, (uint32_t)first,
+                                                                   (uint32_t)chunk, xyzz, prefix);
+  }
+  const hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(xyzz);
+  (void)hipFree(prefix);
+  ZG_HIP(ctx, e1);
+  ZG_HIP(ctx, e2);
   return ZG16_OK;
 }
 template zg16_status msm_build_table<Fq>(zg16_ctx*, Affine<Fq>*, size_t, uint32_t, uint32_t);
