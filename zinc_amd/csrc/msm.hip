@@ -741,43 +741,6 @@ size_t msm_direct_max() {
   return lg <= 0 ? 0 : (size_t)1 << (lg > 16 ? 16 : lg);
 }
 
-// One thread per (point, window): 2^(5 w) * P by doublings, then its sixteen multiples.
-template <class F>
-__global__ __launch_bounds__(256, 1) void k_build_direct(const Affine<F>* __restrict__ pts, uint32_t n,
-                                                         Affine<F>* __restrict__ out) {
-  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= n * DIRECT_W) return;
-  const uint32_t w = idx / n, k = idx - w * n;
-  const Affine<F> p = pts[k];
-  Affine<F>* dst = out + ((size_t)w * DIRECT_M * n + k);
-  if (p.is_inf()) {  // an identity base stays one in every multiple (and is reported when a digit asks for it)
-    for (uint32_t j = 0; j < DIRECT_M; j++) dst[(size_t)j * n] = p;
-    return;
-  }
-  XYZZ<F> acc = XYZZ<F>::from_affine(p);
-  for (uint32_t d = 0; d < w * DIRECT_C; d++) acc = dbl(acc);
-  const Affine<F> base = to_affine(acc);
-  dst[0] = MsmOps<F>::to_internal(base);
-  for (uint32_t j = 1; j < DIRECT_M; j++) {
-    add_mixed(acc, base);
-    dst[(size_t)j * n] = MsmOps<F>::to_internal(to_affine(acc));
-  }
-}
-
-template <class F>
-zg16_status msm_build_direct(zg16_ctx* ctx, const Affine<F>* points, size_t n, Affine<F>** out) {
-  *out = nullptr;
-  if (!n || n > msm_direct_max()) return ZG16_OK;
-  const size_t entries = n * DIRECT_W * DIRECT_M;
-  ZG_HIP(ctx, hipMalloc((void**)out, entries * sizeof(Affine<F>)));
-  k_build_direct<F><<<(unsigned)((n * DIRECT_W + 255) / 256), 256, 0, ctx->stream>>>(points, (uint32_t)n, *out);
-  ZG_HIP(ctx, hipGetLastError());
-  ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return ZG16_OK;
-}
-template zg16_status msm_build_direct<Fq>(zg16_ctx*, const Affine<Fq>*, size_t, Affine<Fq>**);
-template zg16_status msm_build_direct<Fq2>(zg16_ctx*, const Affine<Fq2>*, size_t, Affine<Fq2>**);
-
 // Job blockIdx.y: every logical thread adds the looked-up multiples of a contiguous share of the job's
 // (window, term) pairs, the workgroup tree-adds, one partial per workgroup at part[job * gridDim.x + blockIdx.x].
 template <class F>
@@ -862,12 +825,20 @@ __global__ __launch_bounds__(256, kMinWaves<F>) void k_table_windows(const Affin
   }
 }
 
+// (group: 0 for a window table -- thread first + j owns point i = first + j.  For a direct table the threads are
+// (window, point) pairs t = w * npts + k whose W entries start at slot (w * group) * npts + k, npts apart.)
+ZG_D uint32_t table_slot(uint32_t t, uint32_t group, uint32_t npts) {
+  return group ? (t / npts) * group * npts + t % npts : t;
+}
+
 template <class F>
 __global__ __launch_bounds__(256, 1) void k_table_affine(Affine<F>* __restrict__ table, uint32_t n, uint32_t stride,
                                                          uint32_t W, uint32_t first, uint32_t chunk,
-                                                         const XYZZ<F>* __restrict__ xyzz, F* __restrict__ prefix) {
-  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x, i = first + j;
-  if (j >= chunk || i >= n) return;
+                                                         const XYZZ<F>* __restrict__ xyzz, F* __restrict__ prefix,
+                                                         uint32_t group, uint32_t npts) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= chunk || first + j >= n) return;
+  const uint32_t i = table_slot(first + j, group, npts);
   F run = F::one();
   for (uint32_t w = 1; w < W; w++) {
     const XYZZ<F> a = xyzz[(size_t)(w - 1) * chunk + j];
@@ -987,7 +958,7 @@ zg16_status msm_build_table(zg16_ctx* ctx, Affine<F>* table, size_t n, uint32_t 
     k_table_windows<F><<<(unsigned)((here * MsmOps<F>::LP + 255) / 256), 256, 0, st>>>(table, (uint32_t)n, W, c * step, (uint32_t)first,
                                                                                  (uint32_t)chunk, xyzz);
     k_table_affine<F><<<(unsigned)((here + 255) / 256), 256, 0, st>>>(table, (uint32_t)n, (uint32_t)n, W, (uint32_t)first,
-                                                                   (uint32_t)chunk, xyzz, prefix);
+                                                                   (uint32_t)chunk, xyzz, prefix, 0, 0);
   }
   const hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(ctx->stream);
   (void)hipFree(xyzz);
@@ -998,6 +969,81 @@ zg16_status msm_build_table(zg16_ctx* ctx, Affine<F>* table, size_t n, uint32_t 
 }
 template zg16_status msm_build_table<Fq>(zg16_ctx*, Affine<Fq>*, size_t, uint32_t, uint32_t);
 template zg16_status msm_build_table<Fq2>(zg16_ctx*, Affine<Fq2>*, size_t, uint32_t, uint32_t);
+
+// ---- direct tables, built -----------------------------------------------------------------------------------
+// direct[(w * 16 + m) * n + k] = (m + 1) * 2^(5 w) * P_k.  Built like a window table, twice over: the 52 window
+// bases 2^(5 w) * P_k are a window table of width 5 whose windows lie 16 n slots apart (k_table_windows /
+// k_table_affine: one chain of 255 doublings and one inversion per point); then one logical thread per (window,
+// point) adds the base to itself fifteen times (k_direct_multiples, 29-bit arithmetic) and k_table_affine brings
+// those fifteen multiples back to affine form with ONE inversion.  (The first version gave every (window, point)
+// thread its own 5 w doublings from P_k and an inversion per multiple: 75 ms for the five queries of a 1.8 k-row
+// circuit and 316 ms at 2^14 rows -- more than a hundred proofs' worth of what the table saves.)
+template <class F>
+__global__ __launch_bounds__(256, kMinWaves<F>) void k_direct_multiples(const Affine<F>* __restrict__ direct, uint32_t total,
+                                                                        uint32_t npts, uint32_t first, uint32_t chunk,
+                                                                        XYZZ<F>* __restrict__ xyzz) {
+  using Ops = MsmOps<F>;
+  const uint32_t j = (blockIdx.x * blockDim.x + threadIdx.x) / Ops::LP, t = first + j;
+  if (j >= chunk || t >= total) return;  // (the lanes of a pair share j)
+  typename Ops::Aff base;
+  typename Ops::Pt acc = Ops::inf();
+  const bool finite = Ops::load_base(direct + table_slot(t, DIRECT_M, npts), false, &base);
+  if (finite) Ops::madd(acc, base);
+  for (uint32_t m = 1; m < DIRECT_M; m++) {
+    if (finite) Ops::madd(acc, base);  // (m = 1 adds the base to itself: the addition's doubling case)
+    Ops::store_std(xyzz + (size_t)(m - 1) * chunk + j, acc);
+  }
+}
+
+template <class F>
+zg16_status msm_build_direct(zg16_ctx* ctx, const Affine<F>* points, size_t n, Affine<F>** out) {
+  *out = nullptr;
+  if (!n || n > msm_direct_max()) return ZG16_OK;
+  const size_t entries = n * DIRECT_W * DIRECT_M, total = n * DIRECT_W;
+  hipStream_t st = ctx->stream;
+  Affine<F>* direct = nullptr;
+  ZG_HIP(ctx, hipMalloc((void**)&direct, entries * sizeof(Affine<F>)));
+  // scratch: the larger of the two uses -- DIRECT_W - 1 window bases per point, DIRECT_M - 1 multiples per chunk
+  // of (window, point) threads
+  size_t chunk = (size_t)1 << 18;
+  if (chunk > total) chunk = total;
+  const size_t slots = std::max((size_t)(DIRECT_W - 1) * n, (size_t)(DIRECT_M - 1) * chunk);
+  XYZZ<F>* xyzz = nullptr;
+  F* prefix = nullptr;
+  hipError_t e = hipMalloc((void**)&xyzz, slots * sizeof(XYZZ<F>));
+  if (e == hipSuccess) e = hipMalloc((void**)&prefix, slots * sizeof(F));
+  if (e == hipSuccess) e = hipMemcpyAsync(direct, points, n * sizeof(Affine<F>), hipMemcpyDeviceToDevice, st);
+  if (e == hipSuccess) {
+    // window bases: slot (w * 16) * n + k
+    k_table_convert<F><<<(unsigned)((n + 255) / 256), 256, 0, st>>>(direct, (uint32_t)n);
+    k_table_windows<F><<<(unsigned)((n * MsmOps<F>::LP + 255) / 256), 256, 0, st>>>(direct, (uint32_t)n, DIRECT_W, DIRECT_C, 0,
+                                                                              (uint32_t)n, xyzz);
+    k_table_affine<F><<<(unsigned)((n + 255) / 256), 256, 0, st>>>(direct, (uint32_t)n, (uint32_t)(DIRECT_M * n), DIRECT_W, 0,
+                                                                (uint32_t)n, xyzz, prefix, 0, 0);
+    // the other fifteen multiples of every base: slots n apart
+    for (size_t first = 0; first < total; first += chunk) {
+      const size_t here = total - first < chunk ? total - first : chunk;
+      k_direct_multiples<F><<<(unsigned)((here * MsmOps<F>::LP + 255) / 256), 256, 0, st>>>(direct, (uint32_t)total, (uint32_t)n,
+                                                                                      (uint32_t)first, (uint32_t)chunk, xyzz);
+      k_table_affine<F><<<(unsigned)((here + 255) / 256), 256, 0, st>>>(direct, (uint32_t)total, (uint32_t)n, DIRECT_M,
+                                                                     (uint32_t)first, (uint32_t)chunk, xyzz, prefix, DIRECT_M,
+                                                                     (uint32_t)n);
+    }
+    e = hipGetLastError();
+  }
+  const hipError_t e2 = hipStreamSynchronize(st);
+  (void)hipFree(xyzz);
+  (void)hipFree(prefix);
+  if (e != hipSuccess || e2 != hipSuccess) {
+    (void)hipFree(direct);
+    ZG_HIP(ctx, e);
+    ZG_HIP(ctx, e2);
+  }
+  *out = direct;
+  return ZG16_OK;
+}
+template zg16_status msm_build_direct<Fq>(zg16_ctx*, const Affine<Fq>*, size_t, Affine<Fq>**);
+template zg16_status msm_build_direct<Fq2>(zg16_ctx*, const Affine<Fq2>*, size_t, Affine<Fq2>**);
 
 // How a set of 2^bits buckets is folded on the device: R*H buckets -> U (R) and V (H), then
 // U -> r1 + h1 points and V -> r2 + h2 points, all sizes powers of two (logarithms held here).
