@@ -329,6 +329,21 @@ def test_verify_proof_golden(idx):
     assert e.value.status_name == "MalformedKey"
 
 
+def test_verify_fast_pairing_equals_plain_pairing():
+    """The pairing that runs (twist arithmetic, one shared Miller loop, Frobenius constants, x-power final
+    exponentiation) against the plain one kept beside it (E(Fq12) arithmetic, power by (q^12 - 1) / r):
+    ZG16_VERIFY_CHECK=1 makes zg16_verify_proof compute both and fail unless the Miller products and the
+    exponentiations agree element for element -- on the accepted fixture proofs and on every rejected variant of
+    test_verify_proof_golden.  The switch is read once per process, hence the child process."""
+    import subprocess
+    import sys
+    env = dict(os.environ, ZG16_VERIFY_CHECK="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", os.path.abspath(__file__), "-k",
+                        "test_verify_proof_golden"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "3 passed" in r.stdout
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_gloo_sharded_h_schedule(world):
     """The three-round schedule that keeps a, b, c sharded through the whole H computation, over gloo ranks on the
