@@ -24,10 +24,13 @@ def gather_partials(partial, world, rank, device=None):
     mine = torch.frombuffer(bytearray(bytes(partial)), dtype=torch.uint8)
     if device is not None and dist.get_backend() != "gloo":
         mine = mine.to(device)
-    outs = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(outs, mine)
-    host = b"".join(t.cpu().numpy().tobytes() for t in outs)
-    return (_lib.Partial * world).from_buffer_copy(host)
+    # one flat receive buffer, so that a single copy brings every rank's partial back to the host
+    flat = torch.empty(world * mine.numel(), dtype=torch.uint8, device=mine.device)
+    try:
+        dist.all_gather_into_tensor(flat, mine)
+    except (RuntimeError, NotImplementedError, AttributeError):
+        dist.all_gather(list(flat.chunk(world)), mine)
+    return (_lib.Partial * world).from_buffer_copy(flat.cpu().numpy().tobytes())
 
 
 def finish(pk_view, partials, n, r_mont, s_mont):
