@@ -457,6 +457,10 @@ struct Assembly {
   Fr rc, sc;  // canonical r, s
   G1XYZZ A, c_part;
   G2XYZZ B;
+  // A and B in affine form, converted as soon as they are complete (beside the h multiexp, not after it)
+  G1Affine A_affine;
+  G2Affine B_affine;
+  bool have_A = false, have_B = false;
   const FixedBaseTable<Fq>* delta1_table = nullptr;   // optional (a key handle has them)
   const FixedBaseTable<Fq2>* delta2_table = nullptr;
   // needs nothing from the GPU: alpha + r*delta and beta + s*delta
@@ -466,12 +470,18 @@ struct Assembly {
     B = delta2_table ? delta2_table->mul(sc.v) : scalar_mul_w4(G2XYZZ::from_affine(delta2), sc.v);
     add_mixed(B, beta2);
   }
-  void with_g2(const G2XYZZ& qb2) { add_full(B, qb2); }
+  void with_g2(const G2XYZZ& qb2) {
+    add_full(B, qb2);
+    B_affine = to_affine(B);
+    have_B = true;
+  }
   void with_g1(const G1XYZZ& qa, const G1XYZZ& qb1) {
     add_full(A, qa);
     G1XYZZ b1 = qb1;
     add_mixed(b1, beta1);
     c_part = double_scalar_mul(A, sc.v, b1, rc.v);
+    A_affine = to_affine(A);
+    have_A = true;
   }
   void early(const G1XYZZ& qa, const G1XYZZ& qb1, const G2XYZZ& qb2) {
     key_terms();
@@ -481,8 +491,8 @@ struct Assembly {
   void finish(const G1XYZZ& hl, zg16_proof* out) const {
     G1XYZZ C = c_part;
     add_full(C, hl);
-    const G1Affine Aa = to_affine(A), Ca = to_affine(C);
-    const G2Affine Ba = to_affine(B);
+    const G1Affine Aa = have_A ? A_affine : to_affine(A), Ca = to_affine(C);
+    const G2Affine Ba = have_B ? B_affine : to_affine(B);
     memcpy(out->a, &Aa, 64);
     memcpy(out->b, &Ba, 128);
     memcpy(out->c, &Ca, 64);
