@@ -523,6 +523,40 @@ def test_prove_vs_cpu_oracle(gpu_ctx, log_rows, dense):
     mat.free()
 
 
+@pytest.mark.parametrize("rows,n_pub,dense,pack", [
+    (37, 1, False, 0), (300, 3, True, 31), (1025, 16, False, 64), (4095, 2, False, 248), (4097, 5, True, 100),
+    (9001, 16, False, 248), (20000, 7, False, 17), (40000, 1, True, 248)])
+def test_prove_ragged_sizes_vs_cpu_oracle(gpu_ctx, rows, n_pub, dense, pack):
+    """Row counts that are not powers of two (domains padded with zero rows, both sides of the one-workgroup
+    transform limit 2^12 and of the direct-table limit 2^14), few and many public inputs, short and long packing
+    rows, r and s of full size: GPU proof == proof of the CPU restatement of bellman, and the library's verifier
+    accepts it against the circuit's public inputs."""
+    from oracle import cpu_binding as cb
+    from zinc_amd import workload
+    from zinc_amd.groth16 import verify_proof
+    from zinc_amd.fields import mont_to_ints
+    circ = workload.SyntheticCircuit(rows, n_pub=n_pub, dense=dense, pack_width=pack, seed=(rows, n_pub, 11, 13))
+    assert circ.satisfied()
+    params = workload.generate_parameters(gpu_ctx, circ, dict(k1=3, k2=5, alpha=rows + 7, beta=11, gamma=13, delta=17, tau=19 + n_pub))
+    r1cs = circ.r1cs()
+    zi, za = circ.witness()
+    rs = ints_to_mont([pow(7, rows, R_MOD), pow(5, rows + 1, R_MOD)], R_MOD)
+    st, want, _ = cb.prove(params, r1cs, zi, za, rs[0], rs[1], threads=8)
+    assert st == 0
+    key, mat = params.upload(gpu_ctx), r1cs.upload(gpu_ctx)
+    try:
+        got = prove_recorded(gpu_ctx, key, mat, zi, za, rs[0], rs[1])
+        for g, w in zip((got.raw.a, got.raw.b, got.raw.c), want):
+            assert np.array_equal(np.frombuffer(bytes(g), dtype=np.uint64), w)
+        public = mont_to_ints(zi[1:], R_MOD)
+        assert verify_proof(params, got, public)
+        if public:
+            assert not verify_proof(params, got, [(public[0] + 1) % R_MOD] + public[1:])
+    finally:
+        key.free()
+        mat.free()
+
+
 @pytest.mark.parametrize("log_rows", [8, 13])
 def test_graph_replay_gives_the_same_proofs(gpu_ctx, log_rows):
     """A proof replayed as a captured HIP graph equals the plainly launched one: first call plain, second captured,
