@@ -557,6 +557,47 @@ def test_prove_ragged_sizes_vs_cpu_oracle(gpu_ctx, rows, n_pub, dense, pack):
         mat.free()
 
 
+@pytest.mark.parametrize("kind", ["zeros", "ones", "minus_ones", "uniform", "sparse"])
+@pytest.mark.parametrize("rows", [600, 1 << 15])
+def test_prove_degenerate_witnesses_vs_cpu_oracle(gpu_ctx, kind, rows):
+    """Witness vectors a synthesizer would never produce -- every aux value zero (every multiexp sums nothing, H is
+    zero), one (everything goes down the unit-scalar path), r - 1, uniform, or a few non-zero values in a sea of zeros.
+    They do not satisfy the circuit; bellman's create_proof does not look (the division by Z on the coset is then
+    simply not exact) and neither does this library: the proof must still equal the CPU restatement's bit for bit."""
+    from oracle import cpu_binding as cb
+    from zinc_amd import workload
+    circ = workload.SyntheticCircuit(rows, n_pub=2, seed=(rows, 5, 6, 7))
+    params = workload.generate_parameters(gpu_ctx, circ, dict(k1=2, k2=3, alpha=5, beta=7, gamma=11, delta=13, tau=17))
+    r1cs = circ.r1cs()
+    zi, za = circ.witness()
+    rng = np.random.default_rng(rows)
+    n = za.shape[0]
+    if kind == "zeros":
+        za = np.zeros_like(za)
+    elif kind == "ones":
+        za = np.ascontiguousarray(np.repeat(ints_to_mont([1], R_MOD), n, axis=0))
+    elif kind == "minus_ones":
+        za = np.ascontiguousarray(np.repeat(ints_to_mont([R_MOD - 1], R_MOD), n, axis=0))
+    elif kind == "uniform":
+        za = ints_to_mont([pow(int(x), 5, R_MOD) for x in rng.integers(2, 1 << 62, size=n)], R_MOD)
+    else:
+        za = np.zeros_like(za)
+        idx = rng.choice(n, size=7, replace=False)
+        za[idx] = ints_to_mont([pow(3, int(i) + 2, R_MOD) for i in idx], R_MOD)
+    za = np.ascontiguousarray(za, dtype=np.uint64)
+    rs = ints_to_mont([R_MOD - 2, 1], R_MOD)
+    st, want, _ = cb.prove(params, r1cs, zi, za, rs[0], rs[1], threads=8)
+    assert st == 0
+    key, mat = params.upload(gpu_ctx), r1cs.upload(gpu_ctx)
+    try:
+        got = prove_recorded(gpu_ctx, key, mat, zi, za, rs[0], rs[1])
+        for g, w in zip((got.raw.a, got.raw.b, got.raw.c), want):
+            assert np.array_equal(np.frombuffer(bytes(g), dtype=np.uint64), w)
+    finally:
+        key.free()
+        mat.free()
+
+
 @pytest.mark.parametrize("log_rows", [8, 13])
 def test_graph_replay_gives_the_same_proofs(gpu_ctx, log_rows):
     """A proof replayed as a captured HIP graph equals the plainly launched one: first call plain, second captured,
