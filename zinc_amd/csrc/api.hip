@@ -205,6 +205,8 @@ void zg16_ctx_destroy(zg16_ctx* ctx) {
   ntt_free_hshard_tables(ctx);
   for (auto& s : ctx->scratch)
     if (s) (void)hipFree(s);
+  for (auto& t : ctx->fb_table)
+    if (t) (void)hipFree(t);
   for (auto& e : ctx->ev)
     if (e) (void)hipEventDestroy(e);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);

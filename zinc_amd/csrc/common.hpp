@@ -68,6 +68,12 @@ struct zg16_ctx {
   size_t scratch_bytes[10] = {};
   zg16_timings timings = {};
   zg::HandleCache* cache = nullptr;  // created on first use (zg16_pk_cached / zg16_r1cs_cached)
+  // The affine byte-window table of the last G1 ([0]) and G2 ([1]) base a fixed-base multiplication used: key
+  // generation multiplies seven scalar vectors by the same two generators, and building a table is a chain of
+  // ~500 dependent group operations on 32 lanes (6 ms for G1, 30 ms for G2) whatever the vector's length.
+  void* fb_table[2] = {};
+  unsigned char fb_base[2][128] = {};
+  bool fb_valid[2] = {};
 };
 
 namespace zg {

@@ -57,15 +57,25 @@ static zg16_status fixed_base_device(zg16_ctx* ctx, const Affine<F>& b, const Fr
   if (n >= 0xffffffffull) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "too many scalars");
   if (!n) return ZG16_OK;
   const int tn = FB_WINDOWS * FB_DIGITS;
+  constexpr int g = sizeof(F) > sizeof(Fq) ? 1 : 0;
   char* buf;
   const size_t t_x = (size_t)tn * sizeof(XYZZ<F>), t_a = (size_t)tn * sizeof(Affine<F>), o_b = n * sizeof(Affine<F>);
-  ZG_TRY(scratch_get(ctx, 5, t_x + t_a + o_b + 1024, (void**)&buf));
+  ZG_TRY(scratch_get(ctx, 5, t_x + o_b + 1024, (void**)&buf));
   XYZZ<F>* tx = (XYZZ<F>*)buf;
-  Affine<F>* ta = (Affine<F>*)(buf + t_x);
-  Affine<F>* dout = (Affine<F>*)(buf + t_x + t_a);
+  Affine<F>* dout = (Affine<F>*)(buf + t_x);
   hipStream_t st = ctx->stream;
-  k_fb_table_rows<F><<<1, 64, 0, st>>>(b, tx);
-  k_fb_table_affine<F><<<(tn + 255) / 256, 256, 0, st>>>(tx, ta, tn);
+  // the table of this base, kept with the context from one call to the next
+  if (!ctx->fb_table[g]) ZG_HIP(ctx, hipMalloc(&ctx->fb_table[g], t_a));
+  Affine<F>* ta = (Affine<F>*)ctx->fb_table[g];
+  static_assert(sizeof(Affine<F>) <= sizeof(ctx->fb_base[g]), "base point larger than its cache key");
+  if (!ctx->fb_valid[g] || memcmp(ctx->fb_base[g], &b, sizeof b) != 0) {
+    ctx->fb_valid[g] = false;
+    k_fb_table_rows<F><<<1, 64, 0, st>>>(b, tx);
+    k_fb_table_affine<F><<<(tn + 255) / 256, 256, 0, st>>>(tx, ta, tn);
+    ZG_HIP(ctx, hipGetLastError());
+    memcpy(ctx->fb_base[g], &b, sizeof b);
+    ctx->fb_valid[g] = true;
+  }
   k_fb_mul<F><<<(unsigned)((n + 255) / 256), 256, 0, st>>>(ta, d_scalars, dout, (uint32_t)n);
   ZG_HIP(ctx, hipGetLastError());
   ZG_HIP(ctx, hipMemcpyAsync(out, dout, o_b, hipMemcpyDeviceToHost, st));
