@@ -594,21 +594,34 @@ static zg16_status prove_partial_impl(zg16_ctx* ctx, const zg16_pk* pk, const zg
   if (!h_external) ZG_TRY(h_pipeline_device(ctx, a, b, c, r->log_m));
   ZG_HIP(ctx, hipEventRecord(ev[E_NTT], st));
   mark("rows and transforms enqueued");
+  // b_g1 and b_g2 multiply the same scalars through the same map: when their tables have the same digit width the
+  // witness launch sorts for both (its group 2) and the G2 launch walks that part of its entries.  The witness
+  // launch is then queued first; ZG16_SHARE_SORT=0 keeps two sorts.
+  static const bool share_wanted = !(getenv("ZG16_SHARE_SORT") && atoi(getenv("ZG16_SHARE_SORT")) == 0);
+  MsmSortShare share;
+  share.group = 2;
+  share.sorted = ev[10];
+  const bool try_share = tables && share_wanted && pk->table_c == pk->table_c_g2 && pk->hi_b > pk->lo_b;
+  auto witness_g1 = [&]() -> zg16_status {
+    if (!tables) return ZG16_OK;
+    hipStream_t early = serial ? st : ctx->early_stream;
+    ZG_HIP(ctx, hipStreamWaitEvent(early, ev[E_Z], 0));
+    const MsmStreams ms = {early, nullptr, nullptr, nullptr};
+    ZG_TRY(msm_launch<Fq>(ctx, ms, 6, pinned + 2 * MSM_PINNED_BYTES, jobs_z, 3, 3, &pend_z, nullptr, try_share ? &share : nullptr));
+    ZG_HIP(ctx, hipEventRecord(ev[E_Z_END], early));
+    return ZG16_OK;
+  };
+  if (try_share) ZG_TRY(witness_g1());
   {
     ZG_HIP(ctx, hipStreamWaitEvent(aux, ev[E_Z], 0));
     ZG_HIP(ctx, hipEventRecord(ev[E_G2_BEGIN], aux));
     MsmJob<Fq2> jb = {pk->b2, z, r->b_map + pk->lo_b, pk->hi_b - pk->lo_b, stride(pk->lo_b, pk->hi_b), pk->table_c_g2, 0, pk->b2_d, pk->table_step};
     const MsmStreams ms = {aux, nullptr, nullptr, nullptr};
-    ZG_TRY(msm_launch<Fq2>(ctx, ms, 2, pinned + MSM_PINNED_BYTES, &jb, 1, 1, &pend_g2));
+    ZG_TRY(msm_launch<Fq2>(ctx, ms, 2, pinned + MSM_PINNED_BYTES, &jb, 1, 1, &pend_g2, nullptr, nullptr,
+                           try_share && share.valid ? &share : nullptr));
     ZG_HIP(ctx, hipEventRecord(ev[E_G2_END], aux));
   }
-  if (tables) {
-    hipStream_t early = serial ? st : ctx->early_stream;
-    ZG_HIP(ctx, hipStreamWaitEvent(early, ev[E_Z], 0));
-    const MsmStreams ms = {early, nullptr, nullptr, nullptr};
-    ZG_TRY(msm_launch<Fq>(ctx, ms, 6, pinned + 2 * MSM_PINNED_BYTES, jobs_z, 3, 3, &pend_z));
-    ZG_HIP(ctx, hipEventRecord(ev[E_Z_END], early));
-  }
+  if (!try_share) ZG_TRY(witness_g1());
 
   if (tables) {
     const MsmStreams ms = {st, serial ? nullptr : ctx->side_stream, ev[8], ev[9]};

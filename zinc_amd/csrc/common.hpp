@@ -259,9 +259,25 @@ struct MsmWorkspace {
   char* ptr;
   size_t bytes;
 };
+// One sort for two multiexps over the same scalars (b_g1 and b_g2 of a proof: same witness values through the same
+// gather map, different bases).  A launch given `lend` fills it after its sort -- where the bucket-sorted entries and
+// the bucket offsets lie, what shape they have, and an event recorded behind the sort; a launch given that record as
+// `borrow` (one job, one group, the same digit width and table step, the terms of the lender's group `group`) skips
+// its own sort and walks the lender's entries of that group instead.  valid stays false when the lender did not
+// sort (no terms, or a direct-table sum): the borrower is then launched without it.
+struct MsmSortShare {
+  bool valid = false;
+  const void* rec = nullptr;      // uint2 entries, bucket-sorted, unit-scalar entries behind them
+  const uint32_t* off = nullptr;  // nb + G + 1 offsets into rec
+  uint32_t nb = 0, c = 0, f = 0, B = 0;
+  uint32_t group = 0;             // the lender's group the borrower sums (set by the caller before the launch)
+  uint32_t term_start = 0, term_count = 0;  // that group's range of the lender's term list
+  hipEvent_t sorted = nullptr;    // set by the caller; recorded by the lender
+};
 template <class F>
 zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, void* pinned, const MsmJob<F>* jobs,
-                       int njobs, int ngroups, MsmPending* pend, const MsmWorkspace* fixed = nullptr);
+                       int njobs, int ngroups, MsmPending* pend, const MsmWorkspace* fixed = nullptr,
+                       MsmSortShare* lend = nullptr, const MsmSortShare* borrow = nullptr);
 template <class F>
 zg16_status msm_collect(zg16_ctx* ctx, const MsmPending* pend, XYZZ<F>* out);
 

@@ -456,21 +456,26 @@ ZG_D uint32_t piece_slot(uint32_t s, uint32_t K, uint32_t piece) {
 // entries in an LDS ring two ahead, no load left inside the loop.  Bit-identical, and 3 % SLOWER at 2^20 rows: with
 // four waves per SIMD the gather latency is already hidden -- the fifth of the issue slots this kernel leaves empty
 // is the 64-bit multiply-add's own issue rate, two thirds of the 32-bit rate, not a wait for memory.)
+//
+// off points at the offsets of the nb buckets this launch sums, whose keys in the entries are key0 .. key0 + nb - 1:
+// the whole sorted list (key0 = 0, off[0] = 0) or, when the sort was another launch's, one group's part of it.
 template <class F>
 __global__ __launch_bounds__(256, kMinWaves<F>) void k_accumulate(JobTable<F> jt, uint32_t nb, uint32_t lanes,
                                                                   const uint2* __restrict__ rec,
-                                                                  const uint32_t* __restrict__ off,
+                                                                  const uint32_t* __restrict__ off, uint32_t key0,
                                                                   typename MsmOps<F>::PtMem* __restrict__ pts_out,
                                                                   typename MsmOps<F>::PtMem* __restrict__ bucket_sum,
                                                                   uint32_t* __restrict__ err_flag) {
   using O = MsmOps<F>;
   const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) / O::LP;
-  const uint32_t nslots = off[nb];  // digit entries; the unit-scalar entries behind them go to k_sum_range
+  const uint32_t e0 = off[0];
+  const uint32_t nslots = off[nb] - e0;  // digit entries; the unit-scalar entries behind them go to k_sum_range
+  if (blockIdx.x == 0 && threadIdx.x == 0) err_flag[3] = nslots;  // the additions of this launch, for the host's counters
   const uint32_t K = chunk_len(nslots, lanes, nb);
   const uint64_t lo64 = (uint64_t)t * K;
   if (lo64 >= nslots) return;
-  const uint32_t lo = (uint32_t)lo64;
-  const uint32_t hi = nslots - lo > K ? lo + K : nslots;
+  const uint32_t lo = e0 + (uint32_t)lo64;
+  const uint32_t hi = nslots - (uint32_t)lo64 > K ? lo + K : e0 + nslots;
   uint32_t cur = KEY_INVALID;
   typename O::Pt acc = O::inf();
   bool first_run = true;
@@ -488,7 +493,10 @@ __global__ __launch_bounds__(256, kMinWaves<F>) void k_accumulate(JobTable<F> jt
   for (uint32_t i = lo; i < hi; i++) {
     const uint2 rc = rec[i];
     const uint32_t kw = rc.x, e = rc.y;
-    const uint32_t k = kw & KEY_MASK;
+    // (a key outside this launch's buckets can only come from a damaged entry or a wrong offset table: clamped, so
+    // that such a bug gives a wrong sum instead of a read far outside `off`)
+    const uint32_t krel = (kw & KEY_MASK) - key0;
+    const uint32_t k = krel < nb ? krel : nb - 1;
     if (k != cur) {
       if (cur != KEY_INVALID) flush();
       cur = k;
@@ -516,11 +524,12 @@ __global__ __launch_bounds__(256, kMinWaves<F>) void k_combine(uint32_t nb, uint
   using O = MsmOps<F>;
   const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) / O::LP;
   const uint32_t b = t / L, sub = t % L;
-  const uint32_t K = chunk_len(off[nb], lanes, nb);
+  const uint32_t e0 = off[0];  // positions below are counted from the first entry of this launch's buckets
+  const uint32_t K = chunk_len(off[nb] - e0, lanes, nb);
   uint32_t s = 0, pieces = 0;  // pieces == 0: nothing to add here
   if (b < nb) {
-    s = off[b];
-    const uint32_t e = off[b + 1];
+    s = off[b] - e0;
+    const uint32_t e = off[b + 1] - e0;
     if (e > s) {
       const uint32_t n = (e - 1) / K - s / K + 1;
       if (n > LIGHT_PIECES) {
@@ -593,11 +602,12 @@ __global__ __launch_bounds__(256, kMinWaves<F>) void k_heavy(const uint32_t* __r
   using O = MsmOps<F>;
   __shared__ typename O::Pt sh[128];
   const uint32_t n = *heavy_count;
-  const uint32_t K = chunk_len(off[nb], lanes, nb);
+  const uint32_t e0 = off[0];
+  const uint32_t K = chunk_len(off[nb] - e0, lanes, nb);
   const uint32_t lt = threadIdx.x / O::LP, nlt = 256 / O::LP;
   for (uint32_t h = blockIdx.x; h < n; h += gridDim.x) {
     const uint32_t b = heavy_list[h];
-    const uint32_t s = off[b], e = off[b + 1];
+    const uint32_t s = off[b] - e0, e = off[b + 1] - e0;
     const uint32_t pieces = (e - 1) / K - s / K + 1;
     typename O::Pt acc = O::inf();
     for (uint32_t p = lt; p < pieces; p += nlt) O::add(acc, O::load(pts1 + piece_slot(s, K, p)));
@@ -1067,8 +1077,10 @@ static constexpr size_t PINNED_POINTS = 256;
 
 template <class F>
 zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, void* pinned, const MsmJob<F>* jobs,
-                       int njobs, int ngroups, MsmPending* pend, const MsmWorkspace* fixed) {
+                       int njobs, int ngroups, MsmPending* pend, const MsmWorkspace* fixed, MsmSortShare* lend,
+                       const MsmSortShare* borrow) {
   hipStream_t st = ms.main;
+  if (lend) lend->valid = false;
   if (njobs > MAX_JOBS) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "too many multiexp jobs");
   if (ngroups < 1 || ngroups > MAX_JOBS) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "bad multiexp group count");
   JobTable<F> jt = {};
@@ -1168,6 +1180,14 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
   if (nresult * sizeof(XYZZ<F>) + PINNED_POINTS > MSM_PINNED_BYTES)
     return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "multiexp result block too large");
   const uint32_t ncount = sh.nb + sh.G;  // counters: digit buckets, then one unit-scalar bucket per group
+  if (borrow) {
+    if (!borrow->valid || !sh.shared || nj != 1 || sh.G != 1 || borrow->c != sh.c || borrow->f != sh.f || borrow->B != sh.B ||
+        borrow->term_count != n || (uint64_t)(borrow->group + 1) * sh.nb > borrow->nb)
+      return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "this multiexp cannot use the other one's sort (different width, step or terms)");
+    // the entries name the lender's terms
+    jt.start[0] = borrow->term_start;
+    for (int j = 1; j <= MAX_JOBS; j++) jt.start[j] = borrow->term_start + (uint32_t)n;
+  }
 
   // Coarse bins: about 256 (a workgroup's run in a bin is then a few lines long; 1024 bins measured 5 % slower at
   // 2^24 rows), as long as two bins' buckets still fit the LDS counters of the fine passes.
@@ -1239,7 +1259,19 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
 
   ZG_HIP(ctx, hipMemsetAsync(base, 0, o_zero_end, st));  // every counter and flag
   ZG_HIP(ctx, hipMemsetAsync(bsum, 0, (size_t)sh.nb * sizeof(PtMem), st));
-  {
+  // whose sorted entries the kernels below walk: this launch's, or one group's part of the lender's
+  const uint2* walk_rec = rec;
+  const uint32_t* walk_off = off;        // offsets of the nb digit buckets (and the end of the last one)
+  const uint32_t* ones_off = off;        // ones_off[ones_nb + g] .. [ones_nb + g + 1]: the unit-scalar entries of group g
+  uint32_t key0 = 0, ones_nb = sh.nb;
+  if (borrow) {
+    key0 = borrow->group * sh.nb;
+    walk_rec = (const uint2*)borrow->rec;
+    walk_off = borrow->off + key0;
+    ones_off = borrow->off + borrow->group;
+    ones_nb = borrow->nb;
+    ZG_HIP(ctx, hipStreamWaitEvent(st, borrow->sorted, 0));
+  } else {
     KernelTimer kt(ctx, K_MSM_DIGITS, (double)n, st);
     const unsigned fgrid = (unsigned)((max_entries + FINE_TILE - 1) / FINE_TILE);
     k_sort_count<F><<<sgrid, 256, 0, st>>>(jt, sh, ss, wg_hist);
@@ -1255,6 +1287,21 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
     k_scan_fixup<<<(ncount + 1 + 255) / 256, 256, 0, st>>>(off, cursor, ncount, tiles, ntiles);
     k_fine_scatter<<<fgrid, 256, 0, st>>>(rec0, coff, ss, cursor, rec);
   }
+  if (lend && sh.shared && lend->sorted && lend->group < sh.G) {
+    for (int j = 0; j < nj; j++)
+      if (jt.group[j] == lend->group) {
+        lend->term_start = jt.start[j];
+        lend->term_count = jt.start[j + 1] - jt.start[j];
+        lend->valid = true;
+      }
+    lend->rec = rec;
+    lend->off = off;
+    lend->nb = sh.nb;
+    lend->c = sh.c;
+    lend->f = sh.f;
+    lend->B = sh.B;
+    if (lend->valid) ZG_HIP(ctx, hipEventRecord(lend->sorted, st));
+  }
   // Everything below sizes its grid for the largest possible entry count and reads the actual
   // counts from `off` on the device, so the host never waits in the middle of a multiexp.
   // The scalars equal to one: a plain tree sum per group, kept out of the segmented reduction.  It
@@ -1262,7 +1309,7 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
   // follows it, so that its two latency-bound launches do not hold back the accumulation.
   auto unit_sums = [&](hipStream_t so) -> zg16_status {
     KernelTimer kt(ctx, is_g2 ? K_MSM_ONES_G2 : K_MSM_ONES_G1, (double)n, so);
-    k_sum_range<F><<<dim3(ones_blocks, sh.G), 256, 0, so>>>(jt, rec, off, sh.nb, ones_part, err);
+    k_sum_range<F><<<dim3(ones_blocks, sh.G), 256, 0, so>>>(jt, walk_rec, ones_off, ones_nb, ones_part, err);
     k_sum_partials<F><<<sh.G, 256, 0, so>>>(ones_part, ones_blocks, wstd + (size_t)nsets * fold.leaves());
     return ZG16_OK;
   };
@@ -1275,14 +1322,14 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
   {
     // work units (additions actually performed) are added by msm_collect from the entry count
     KernelTimer kt(ctx, is_g2 ? K_MSM_ACC0_G2 : K_MSM_ACC0_G1, 0.0, st);
-    k_accumulate<F><<<lanes * LP / 256, 256, 0, st>>>(jt, sh.nb, lanes, rec, off, pts1, bsum, err);
+    k_accumulate<F><<<lanes * LP / 256, 256, 0, st>>>(jt, sh.nb, lanes, walk_rec, walk_off, key0, pts1, bsum, err);
   }
   {
     KernelTimer kt(ctx, is_g2 ? K_MSM_ACCN_G2 : K_MSM_ACCN_G1, (double)sh.nb, st);
     constexpr int L = 4;
     k_combine<F, L><<<(unsigned)(((size_t)sh.nb * L * LP + 255) / 256), 256, 0, st>>>(
-        sh.nb, lanes, off, pts1, bsum, err + 2, (uint32_t*)(base + o_heavy));
-    k_heavy<F><<<256, 256, 0, st>>>(err + 2, (const uint32_t*)(base + o_heavy), off, sh.nb, lanes, pts1, bsum);
+        sh.nb, lanes, walk_off, pts1, bsum, err + 2, (uint32_t*)(base + o_heavy));
+    k_heavy<F><<<256, 256, 0, st>>>(err + 2, (const uint32_t*)(base + o_heavy), walk_off, sh.nb, lanes, pts1, bsum);
   }
   {
     KernelTimer kt(ctx, is_g2 ? K_MSM_REDUCE_G2 : K_MSM_REDUCE_G1, (double)sh.nb, st);
@@ -1312,7 +1359,7 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
   else
     ZG_TRY(unit_sums(st));
   ZG_HIP(ctx, hipMemcpyAsync(pinned, err, 4, hipMemcpyDeviceToHost, st));
-  ZG_HIP(ctx, hipMemcpyAsync((char*)pinned + 4, off + sh.nb, 4, hipMemcpyDeviceToHost, st));
+  ZG_HIP(ctx, hipMemcpyAsync((char*)pinned + 4, err + 3, 4, hipMemcpyDeviceToHost, st));
   ZG_HIP(ctx, hipMemcpyAsync((char*)pinned + PINNED_POINTS, wstd, nresult * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
   pend->nsets = nsets;
   pend->acc_kernel = is_g2 ? K_MSM_ACC0_G2 : K_MSM_ACC0_G1;
@@ -1399,9 +1446,9 @@ zg16_status msm_collect(zg16_ctx* ctx, const MsmPending* pend, XYZZ<F>* out) {
 }
 
 template zg16_status msm_launch<Fq>(zg16_ctx*, const MsmStreams&, int, void*, const MsmJob<Fq>*, int, int, MsmPending*,
-                                    const MsmWorkspace*);
+                                    const MsmWorkspace*, MsmSortShare*, const MsmSortShare*);
 template zg16_status msm_launch<Fq2>(zg16_ctx*, const MsmStreams&, int, void*, const MsmJob<Fq2>*, int, int, MsmPending*,
-                                     const MsmWorkspace*);
+                                     const MsmWorkspace*, MsmSortShare*, const MsmSortShare*);
 template zg16_status msm_collect<Fq>(zg16_ctx*, const MsmPending*, XYZZ<Fq>*);
 template zg16_status msm_collect<Fq2>(zg16_ctx*, const MsmPending*, XYZZ<Fq2>*);
 
