@@ -26,6 +26,8 @@
 #include <mutex>
 #include <thread>
 
+#include <stdlib.h>
+
 #include "r1cs.hpp"
 
 using namespace zg;
@@ -115,13 +117,11 @@ zg16_status zg16_hshard_stage(zg16_hshard* hs, int stage, const uint64_t* z_in, 
     for (int v = 0; v < 3; v++) ZG_TRY(ntt_cross_device(ctx, work + v * L, hs->log_m, hs->log_g, hs->shard, true));
     char* pinned = (char*)ctx->pinned;
     const uint32_t tc = pk->table_c;
-    {
-      ZG_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, hs->ev_z, 0));
-      MsmJob<Fq2> jb = {pk->b2, z, r->b_map + pk->lo_b, pk->hi_b - pk->lo_b, pk->hi_b - pk->lo_b, pk->table_c_g2, 0, pk->b2_d, pk->table_step};
-      const MsmStreams ms = {ctx->aux_stream, nullptr, nullptr, nullptr};
-      ZG_TRY(msm_launch<Fq2>(ctx, ms, 2, pinned + MSM_PINNED_BYTES, &jb, 1, 1, &hs->pend_g2));
-      ZG_HIP(ctx, hipEventRecord(hs->ev_g2, ctx->aux_stream));
-    }
+    // the witness launch sorts for b_g2 as well when the digit widths agree (see prove_partial_impl)
+    MsmSortShare share;
+    share.group = 2;
+    share.sorted = ctx->ev[10];
+    const bool try_share = tc == pk->table_c_g2 && pk->hi_b > pk->lo_b && !(getenv("ZG16_SHARE_SORT") && atoi(getenv("ZG16_SHARE_SORT")) == 0);
     {
       ZG_HIP(ctx, hipStreamWaitEvent(ctx->early_stream, hs->ev_z, 0));
       const MsmJob<Fq> jobs_z[3] = {
@@ -129,8 +129,16 @@ zg16_status zg16_hshard_stage(zg16_hshard* hs, int stage, const uint64_t* z_in, 
           {pk->a, z, r->a_map + pk->lo_a, pk->hi_a - pk->lo_a, pk->hi_a - pk->lo_a, tc, 1, pk->a_d, pk->table_step},
           {pk->b1, z, r->b_map + pk->lo_b, pk->hi_b - pk->lo_b, pk->hi_b - pk->lo_b, tc, 2, pk->b1_d, pk->table_step}};
       const MsmStreams ms = {ctx->early_stream, nullptr, nullptr, nullptr};
-      ZG_TRY(msm_launch<Fq>(ctx, ms, 6, pinned + 2 * MSM_PINNED_BYTES, jobs_z, 3, 3, &hs->pend_z));
+      ZG_TRY(msm_launch<Fq>(ctx, ms, 6, pinned + 2 * MSM_PINNED_BYTES, jobs_z, 3, 3, &hs->pend_z, nullptr, try_share ? &share : nullptr));
       ZG_HIP(ctx, hipEventRecord(hs->ev_early, ctx->early_stream));
+    }
+    {
+      ZG_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, hs->ev_z, 0));
+      MsmJob<Fq2> jb = {pk->b2, z, r->b_map + pk->lo_b, pk->hi_b - pk->lo_b, pk->hi_b - pk->lo_b, pk->table_c_g2, 0, pk->b2_d, pk->table_step};
+      const MsmStreams ms = {ctx->aux_stream, nullptr, nullptr, nullptr};
+      ZG_TRY(msm_launch<Fq2>(ctx, ms, 2, pinned + MSM_PINNED_BYTES, &jb, 1, 1, &hs->pend_g2, nullptr, nullptr,
+                             try_share && share.valid ? &share : nullptr));
+      ZG_HIP(ctx, hipEventRecord(hs->ev_g2, ctx->aux_stream));
     }
     n_ex = 3;
   } else if (stage == 1) {
