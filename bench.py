@@ -333,7 +333,10 @@ def secondary_block(ctx, d, args, split_for):
         t0 = time.perf_counter()
         params = workload.generate_parameters(ctx, r1cs, TOXIC)
         keygen_s = time.perf_counter() - t0
-        key, mat = params.upload(ctx), r1cs.upload(ctx)
+        t0 = time.perf_counter()
+        key = params.upload(ctx)
+        key_upload_s = time.perf_counter() - t0
+        mat = r1cs.upload(ctx)
         zi, za = pa.witness()
         rs = ints_to_mont([pow(7, 123456789, R_MOD), pow(5, 987654321, R_MOD)], R_MOD)
         try:
@@ -348,7 +351,7 @@ def secondary_block(ctx, d, args, split_for):
         return {"workload": "hand-recorded stand-in for zinc-tester/tests/algorithm/factorial.zn (n = 6 -> 720), %d rows, "
                             "witness from host memory" % r1cs.n_rows,
                 "ms_per_proof": 1e3 * sec, "proofs_timed": 50, "verifies_against_pinned_output": bool(ok),
-                "verify_ms_host": 1e3 * verify_s, "keygen_s": keygen_s}
+                "verify_ms_host": 1e3 * verify_s, "keygen_s": keygen_s, "key_upload_and_tables_s": key_upload_s}
 
     guarded("prove_2p%d" % args.secondary_log_rows, lambda: prove_case(args.secondary_log_rows, False, 3))
     if d.world == 1:
