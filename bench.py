@@ -24,7 +24,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
-# ---- algorithmic work per unit (stated in DESIGN.md) ------------------------------------------
+# ---- algorithmic work per unit ---------------------------------------------------------------
 MAD_PER_FQ_MUL = 136               # 8x8 + 8x8 + 8 32-bit multiply-adds in one CIOS product
 FQ_MUL_PER_G1_MADD = 10            # XYZZ mixed addition: 8M + 2S
 FQ_MUL_PER_G2_MADD = 8 * 3 + 2 * 2  # Fq2 mul = 3 Fq mul (Karatsuba), Fq2 sqr = 2
