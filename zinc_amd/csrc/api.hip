@@ -66,7 +66,8 @@ zg16_status upload_query(zg16_ctx* ctx, Affine<F>** dst, const void* src, size_t
   const size_t windows = table_c ? msm_table_windows(table_c, table_step) : 1;
   ZG_HIP(ctx, hipMalloc((void**)dst, windows * count * sizeof(Affine<F>)));
   if (device_bytes) *device_bytes += windows * count * sizeof(Affine<F>);
-  ZG_HIP(ctx, hipMemcpy(*dst, src, count * sizeof(Affine<F>), hipMemcpyHostToDevice));
+  // (in stream order: with the builders deferred, several queries are in flight on different streams)
+  ZG_HIP(ctx, hipMemcpyAsync(*dst, src, count * sizeof(Affine<F>), hipMemcpyHostToDevice, ctx->stream));
   // small queries also get a direct table of every multiple a digit can ask for (built from the ABI-form points)
   if (table_c) ZG_TRY(msm_build_direct<F>(ctx, *dst, count, direct));
   // fills the other windows (if any) and rewrites every point in the multiexp kernels' packed form
@@ -279,12 +280,40 @@ zg16_status zg::pk_upload_impl(zg16_ctx* ctx, const zg16_pk_view* v, int shard_i
                               {pk->hi_b - pk->lo_b, pk->table_c_g2, 128}};
     pk->table_step = msm_table_step(tq, 5);
   }
-  ZG_TRY(upload_query<Fq>(ctx, &pk->h, h_cyclic ? h_gathered.data() : v->h + 8 * pk->lo_h, pk->hi_h - pk->lo_h, pk->table_c_h,
-                          &pk->h_d, &pk->device_bytes, pk->table_step));
-  ZG_TRY(upload_query<Fq>(ctx, &pk->l, v->l + 8 * pk->lo_l, pk->hi_l - pk->lo_l, pk->table_c, &pk->l_d, &pk->device_bytes, pk->table_step));
-  ZG_TRY(upload_query<Fq>(ctx, &pk->a, v->a + 8 * pk->lo_a, pk->hi_a - pk->lo_a, pk->table_c, &pk->a_d, &pk->device_bytes, pk->table_step));
-  ZG_TRY(upload_query<Fq>(ctx, &pk->b1, v->b_g1 + 8 * pk->lo_b, pk->hi_b - pk->lo_b, pk->table_c, &pk->b1_d, &pk->device_bytes, pk->table_step));
-  ZG_TRY(upload_query<Fq2>(ctx, &pk->b2, v->b_g2 + 16 * pk->lo_b, pk->hi_b - pk->lo_b, pk->table_c_g2, &pk->b2_d, &pk->device_bytes, pk->table_step));
+  // The tables of a small key are chains of short kernels on a handful of wavefronts (1-2 ms of latency each, ten of
+  // them per query): the five queries are built side by side on the context's four streams.  Large keys fill the
+  // GPU one query at a time and are built in turn.
+  size_t most = pk->hi_h - pk->lo_h;
+  for (size_t q : {pk->hi_l - pk->lo_l, pk->hi_a - pk->lo_a, pk->hi_b - pk->lo_b}) most = q > most ? q : most;
+  const bool side_by_side = most <= ((size_t)1 << 16) && ctx->stream == ctx->own_stream && !ctx->deferred_frees;
+  std::vector<void*> scratch_to_free;
+  hipStream_t const own = ctx->stream;
+  auto on = [&](hipStream_t s) { ctx->stream = side_by_side ? s : own; };
+  auto upload_all = [&]() -> zg16_status {
+    on(ctx->aux_stream);
+    ZG_TRY(upload_query<Fq2>(ctx, &pk->b2, v->b_g2 + 16 * pk->lo_b, pk->hi_b - pk->lo_b, pk->table_c_g2, &pk->b2_d, &pk->device_bytes, pk->table_step));
+    on(own);
+    ZG_TRY(upload_query<Fq>(ctx, &pk->h, h_cyclic ? h_gathered.data() : v->h + 8 * pk->lo_h, pk->hi_h - pk->lo_h, pk->table_c_h,
+                            &pk->h_d, &pk->device_bytes, pk->table_step));
+    on(ctx->early_stream);
+    ZG_TRY(upload_query<Fq>(ctx, &pk->l, v->l + 8 * pk->lo_l, pk->hi_l - pk->lo_l, pk->table_c, &pk->l_d, &pk->device_bytes, pk->table_step));
+    on(ctx->side_stream);
+    ZG_TRY(upload_query<Fq>(ctx, &pk->a, v->a + 8 * pk->lo_a, pk->hi_a - pk->lo_a, pk->table_c, &pk->a_d, &pk->device_bytes, pk->table_step));
+    on(own);
+    ZG_TRY(upload_query<Fq>(ctx, &pk->b1, v->b_g1 + 8 * pk->lo_b, pk->hi_b - pk->lo_b, pk->table_c, &pk->b1_d, &pk->device_bytes, pk->table_step));
+    return ZG16_OK;
+  };
+  if (side_by_side) ctx->deferred_frees = &scratch_to_free;
+  const zg16_status up = upload_all();
+  ctx->stream = own;
+  ctx->deferred_frees = nullptr;
+  hipError_t drained = hipSuccess;
+  if (side_by_side) {
+    drained = hipDeviceSynchronize();  // every stream, also after a failure: the scratch below is still in use until then
+    for (void* p : scratch_to_free) (void)hipFree(p);
+  }
+  ZG_TRY(up);
+  ZG_HIP(ctx, drained);
   memcpy(&pk->alpha_g1, v->alpha_g1, 64);
   memcpy(&pk->beta_g1, v->beta_g1, 64);
   memcpy(&pk->delta_g1, v->delta_g1, 64);

@@ -74,6 +74,10 @@ struct zg16_ctx {
   void* fb_table[2] = {};
   unsigned char fb_base[2][128] = {};
   bool fb_valid[2] = {};
+  // When set, the table builders (msm_build_table, msm_build_direct) queue their kernels on `stream` and return
+  // without waiting: their scratch allocations are appended here and the caller frees them after it has
+  // synchronised.  zg16_pk_upload uses it to build the tables of a small key's five queries side by side.
+  std::vector<void*>* deferred_frees = nullptr;
 };
 
 namespace zg {

@@ -970,6 +970,12 @@ zg16_status msm_build_table(zg16_ctx* ctx, Affine<F>* table, size_t n, uint32_t 
     k_table_affine<F><<<(unsigned)((here + 255) / 256), 256, 0, st>>>(table, (uint32_t)n, (uint32_t)n, W, (uint32_t)first,
                                                                    (uint32_t)chunk, xyzz, prefix, 0, 0);
   }
+  if (ctx->deferred_frees) {  // the caller waits for the stream and frees the scratch
+    ctx->deferred_frees->push_back(xyzz);
+    ctx->deferred_frees->push_back(prefix);
+    ZG_HIP(ctx, hipGetLastError());
+    return ZG16_OK;
+  }
   const hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(ctx->stream);
   (void)hipFree(xyzz);
   (void)hipFree(prefix);
@@ -1040,6 +1046,12 @@ zg16_status msm_build_direct(zg16_ctx* ctx, const Affine<F>* points, size_t n, A
                                                                      (uint32_t)n);
     }
     e = hipGetLastError();
+  }
+  if (e == hipSuccess && ctx->deferred_frees) {  // the caller waits for the stream and frees the scratch
+    ctx->deferred_frees->push_back(xyzz);
+    ctx->deferred_frees->push_back(prefix);
+    *out = direct;
+    return ZG16_OK;
   }
   const hipError_t e2 = hipStreamSynchronize(st);
   (void)hipFree(xyzz);
