@@ -5,7 +5,7 @@
 // one generator.  Used to build 2^20..2^24-row keys in seconds; not part of the prove path.
 //
 // Method: byte windows.  T[w][d-1] = d * 256^w * base for w < 32, d in 1..255 is built once per
-// call (one lane per window), then every lane sums the 32 table entries its scalar selects with
+// base (sixteen lanes per window; the context keeps the table of the last base), then every lane sums the 32 table entries its scalar selects with
 // mixed additions and converts its own result to affine.
 #include <string.h>
 
@@ -18,14 +18,20 @@ namespace zg {
 
 static constexpr int FB_WINDOWS = 32, FB_DIGITS = 255;
 
+// Lane (w, j), j < 16, writes the multiples 16 j + 1 .. 16 j + 16 of 256^w * base: 8 w doublings to the window's
+// base, four more to its sixteenfold, j additions of that to the segment's start and then the segment's sixteen
+// additions -- a chain of at most 252 doublings and 31 additions instead of 248 and 255 with one lane per window.
 template <class F>
 __global__ void k_fb_table_rows(Affine<F> base, XYZZ<F>* table) {
-  const int w = threadIdx.x;
+  const int w = threadIdx.x >> 4, j = threadIdx.x & 15;
   if (w >= FB_WINDOWS) return;
   XYZZ<F> b = XYZZ<F>::from_affine(base);
   for (int i = 0; i < 8 * w; i++) b = dbl(b);
+  XYZZ<F> b16 = b;
+  for (int i = 0; i < 4; i++) b16 = dbl(b16);
   XYZZ<F> acc = XYZZ<F>::inf();
-  for (int d = 0; d < FB_DIGITS; d++) {
+  for (int i = 0; i < j; i++) add_full(acc, b16);
+  for (int d = 16 * j; d < 16 * j + 16 && d < FB_DIGITS; d++) {
     add_full(acc, b);
     table[w * FB_DIGITS + d] = acc;
   }
@@ -70,7 +76,7 @@ static zg16_status fixed_base_device(zg16_ctx* ctx, const Affine<F>& b, const Fr
   static_assert(sizeof(Affine<F>) <= sizeof(ctx->fb_base[g]), "base point larger than its cache key");
   if (!ctx->fb_valid[g] || memcmp(ctx->fb_base[g], &b, sizeof b) != 0) {
     ctx->fb_valid[g] = false;
-    k_fb_table_rows<F><<<1, 64, 0, st>>>(b, tx);
+    k_fb_table_rows<F><<<1, 16 * FB_WINDOWS, 0, st>>>(b, tx);
     k_fb_table_affine<F><<<(tn + 255) / 256, 256, 0, st>>>(tx, ta, tn);
     ZG_HIP(ctx, hipGetLastError());
     memcpy(ctx->fb_base[g], &b, sizeof b);
@@ -87,9 +93,21 @@ template <class F>
 static zg16_status fixed_base(zg16_ctx* ctx, const uint64_t* base, const uint64_t* scalars, size_t n, uint64_t* out) {
   if (!ctx || !base || (n && (!scalars || !out))) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "bad arguments to fixed-base multiply");
   if (!n) return ZG16_OK;
-  ZG_HIP(ctx, hipSetDevice(ctx->device));
   Affine<F> b;
   memcpy(&b, base, sizeof b);
+  if (n <= 16) {
+    // a handful of scalars (the generators k1 * G, k2 * G of a key generation): a table of 8160 multiples, or even a
+    // kernel launch, costs more than the host's double-and-add
+    for (size_t i = 0; i < n; i++) {
+      Fr s;
+      memcpy(s.v, scalars + 4 * i, 32);
+      const Fr sc = from_mont(s);
+      const Affine<F> r = to_affine(scalar_mul_w4(XYZZ<F>::from_affine(b), sc.v));
+      memcpy(out + i * (sizeof r / 8), &r, sizeof r);
+    }
+    return ZG16_OK;
+  }
+  ZG_HIP(ctx, hipSetDevice(ctx->device));
   Fr* ds;
   ZG_TRY(scratch_get(ctx, 7, n * sizeof(Fr), (void**)&ds));
   ZG_HIP(ctx, hipMemcpyAsync(ds, scalars, n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
