@@ -14,6 +14,8 @@
 //   byte 0 bit 6 = point at infinity (all other bits zero), bit 7 must be clear (compression flag).
 #include <string.h>
 
+#include <vector>
+
 #include <memory>
 
 #define ZG_OUTLINE_FIELD_MUL 1
@@ -136,12 +138,21 @@ struct Cursor {
   }
 };
 
+// The direct table (small queries) and the other windows of a decoded query.
+template <class F>
+static zg16_status query_tables(zg16_ctx* ctx, Affine<F>* pts, size_t count, uint32_t table_c, uint32_t table_step,
+                                Affine<F>** direct) {
+  if (!count) return ZG16_OK;
+  if (table_c) ZG_TRY(msm_build_direct<F>(ctx, pts, count, direct));
+  return msm_build_table<F>(ctx, pts, count, table_c, table_step);
+}
+
 // Decode points [lo, hi) of a vector of `point_bytes`-byte encodings into window 0 of a fresh table and
 // fill the other windows.
 template <class F>
 static zg16_status decode_query(zg16_ctx* ctx, const uint8_t* bytes, size_t lo, size_t hi, int checked, uint32_t table_c,
                                 uint32_t table_step, const Fq2& curve_b, const char* name, Affine<F>** dst,
-                                Affine<F>** direct) {
+                                Affine<F>** direct, bool build_tables) {
   *dst = nullptr;
   *direct = nullptr;
   const size_t count = hi - lo;
@@ -165,8 +176,7 @@ static zg16_status decode_query(zg16_ctx* ctx, const uint8_t* bytes, size_t lo, 
   ZG_HIP(ctx, hipMemcpyAsync(&herr, err, 4, hipMemcpyDeviceToHost, ctx->stream));
   ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (herr) return fail(ctx, ZG16_ERR_MALFORMED_KEY, "%s query: %s", name, decode_text(herr));
-  if (table_c) ZG_TRY(msm_build_direct<F>(ctx, *dst, count, direct));
-  return msm_build_table<F>(ctx, *dst, count, table_c, table_step);
+  return build_tables ? query_tables<F>(ctx, *dst, count, table_c, table_step, direct) : ZG16_OK;
 }
 
 }  // namespace zg
@@ -249,11 +259,42 @@ zg16_status zg16_pk_upload_bytes(zg16_ctx* ctx, const uint8_t* data, size_t len,
                               {pk->hi_b - pk->lo_b, pk->table_c_g2, 128}};
     pk->table_step = msm_table_step(tq, 5);
   }
-  ZG_TRY(decode_query<Fq>(ctx, vec[0], pk->lo_h, pk->hi_h, checked, pk->table_c_h, pk->table_step, curve_b, names[0], &pk->h, &pk->h_d));
-  ZG_TRY(decode_query<Fq>(ctx, vec[1], pk->lo_l, pk->hi_l, checked, pk->table_c, pk->table_step, curve_b, names[1], &pk->l, &pk->l_d));
-  ZG_TRY(decode_query<Fq>(ctx, vec[2], pk->lo_a, pk->hi_a, checked, pk->table_c, pk->table_step, curve_b, names[2], &pk->a, &pk->a_d));
-  ZG_TRY(decode_query<Fq>(ctx, vec[3], pk->lo_b, pk->hi_b, checked, pk->table_c, pk->table_step, curve_b, names[3], &pk->b1, &pk->b1_d));
-  ZG_TRY(decode_query<Fq2>(ctx, vec[4], pk->lo_b, pk->hi_b, checked, pk->table_c_g2, pk->table_step, curve_b, names[4], &pk->b2, &pk->b2_d));
+  // Small keys: decode the five queries, then build their tables side by side on the context's four streams (each
+  // is a chain of short kernels on a handful of wavefronts); large keys fill the GPU one query at a time.
+  size_t most = pk->hi_h - pk->lo_h;
+  for (size_t q : {pk->hi_l - pk->lo_l, pk->hi_a - pk->lo_a, pk->hi_b - pk->lo_b}) most = q > most ? q : most;
+  const bool side_by_side = most <= ((size_t)1 << 16) && ctx->stream == ctx->own_stream && !ctx->deferred_frees;
+  const bool now = !side_by_side;
+  ZG_TRY(decode_query<Fq>(ctx, vec[0], pk->lo_h, pk->hi_h, checked, pk->table_c_h, pk->table_step, curve_b, names[0], &pk->h, &pk->h_d, now));
+  ZG_TRY(decode_query<Fq>(ctx, vec[1], pk->lo_l, pk->hi_l, checked, pk->table_c, pk->table_step, curve_b, names[1], &pk->l, &pk->l_d, now));
+  ZG_TRY(decode_query<Fq>(ctx, vec[2], pk->lo_a, pk->hi_a, checked, pk->table_c, pk->table_step, curve_b, names[2], &pk->a, &pk->a_d, now));
+  ZG_TRY(decode_query<Fq>(ctx, vec[3], pk->lo_b, pk->hi_b, checked, pk->table_c, pk->table_step, curve_b, names[3], &pk->b1, &pk->b1_d, now));
+  ZG_TRY(decode_query<Fq2>(ctx, vec[4], pk->lo_b, pk->hi_b, checked, pk->table_c_g2, pk->table_step, curve_b, names[4], &pk->b2, &pk->b2_d, now));
+  if (side_by_side) {
+    std::vector<void*> scratch_to_free;
+    hipStream_t const own = ctx->stream;
+    auto build_all = [&]() -> zg16_status {
+      ctx->stream = ctx->aux_stream;
+      ZG_TRY(query_tables<Fq2>(ctx, pk->b2, pk->hi_b - pk->lo_b, pk->table_c_g2, pk->table_step, &pk->b2_d));
+      ctx->stream = own;
+      ZG_TRY(query_tables<Fq>(ctx, pk->h, pk->hi_h - pk->lo_h, pk->table_c_h, pk->table_step, &pk->h_d));
+      ctx->stream = ctx->early_stream;
+      ZG_TRY(query_tables<Fq>(ctx, pk->l, pk->hi_l - pk->lo_l, pk->table_c, pk->table_step, &pk->l_d));
+      ctx->stream = ctx->side_stream;
+      ZG_TRY(query_tables<Fq>(ctx, pk->a, pk->hi_a - pk->lo_a, pk->table_c, pk->table_step, &pk->a_d));
+      ctx->stream = own;
+      ZG_TRY(query_tables<Fq>(ctx, pk->b1, pk->hi_b - pk->lo_b, pk->table_c, pk->table_step, &pk->b1_d));
+      return ZG16_OK;
+    };
+    ctx->deferred_frees = &scratch_to_free;
+    const zg16_status built = build_all();
+    ctx->stream = own;
+    ctx->deferred_frees = nullptr;
+    const hipError_t drained = hipDeviceSynchronize();  // also after a failure: the scratch is in use until then
+    for (void* p : scratch_to_free) (void)hipFree(p);
+    ZG_TRY(built);
+    ZG_HIP(ctx, drained);
+  }
   *out = pk.release();
   return ZG16_OK;
 }
