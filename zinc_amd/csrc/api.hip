@@ -69,10 +69,12 @@ zg16_status upload_query(zg16_ctx* ctx, Affine<F>** dst, const void* src, size_t
   // (in stream order: with the builders deferred, several queries are in flight on different streams)
   ZG_HIP(ctx, hipMemcpyAsync(*dst, src, count * sizeof(Affine<F>), hipMemcpyHostToDevice, ctx->stream));
   // small queries also get a direct table of every multiple a digit can ask for (built from the ABI-form points)
-  if (table_c) ZG_TRY(msm_build_direct<F>(ctx, *dst, count, direct));
+  zg16_status st = table_c ? msm_build_direct<F>(ctx, *dst, count, direct) : ZG16_OK;
   // fills the other windows (if any) and rewrites every point in the multiexp kernels' packed form
-  ZG_TRY(msm_build_table<F>(ctx, *dst, count, table_c, table_step));
-  return ZG16_OK;
+  if (st == ZG16_OK) st = msm_build_table<F>(ctx, *dst, count, table_c, table_step);
+  // a failure must not return while the copy above may still be reading the caller's memory
+  if (st != ZG16_OK) (void)hipStreamSynchronize(ctx->stream);
+  return st;
 }
 
 template <class T>
