@@ -116,7 +116,9 @@ void        zg16_pk_free(zg16_pk* pk);
  * `zvm prove` opens with `Parameters::read(file, checked = true)`
  * (zinc-vm/src/zvm/arguments/command/prove.rs:73-76; written at setup.rs:67-69).  The points are decoded,
  * converted to Montgomery form and (with `checked`) validated on the GPU: on the curve, in the prime-order
- * subgroup (G2: multiplication by r), no point at infinity in a query vector.  Any violation or a
+ * subgroup (G2: psi(P) = [6x^2] P with psi the untwist-Frobenius-twist map, which holds exactly when r P = O;
+ * checked = 2 runs the plain multiplication by r instead, the slower form kept as its checker), no point at
+ * infinity in a query vector.  Any violation or a
  * truncated file gives ZG16_ERR_MALFORMED_KEY.  zg16_pk_vk_view fills a view with the handle's
  * verifying-key points (host memory owned by the handle) for zg16_prove_finish. */
 zg16_status zg16_pk_upload_bytes(zg16_ctx* ctx, const uint8_t* data, size_t len, int checked,
@@ -140,6 +142,11 @@ zg16_status zg16_r1cs_upload(zg16_ctx* ctx, const zg16_r1cs_view* view, zg16_r1c
 void        zg16_r1cs_free(zg16_r1cs* r1cs);
 /* popcounts of the density maps: a_aux, b_input, b_aux (any pointer may be NULL). */
 zg16_status zg16_r1cs_density(const zg16_r1cs* r1cs, size_t* a_aux, size_t* b_input, size_t* b_aux);
+/* The shape the matrices were uploaded with (any pointer may be NULL).  zg16_prove reads n_inputs + n_aux witness
+ * elements through the pointers it is given and cannot see how many the caller holds: a host that proves a circuit it
+ * only knows by name (zg16_r1cs_cached with view = NULL) compares its witness lengths with these first and reports
+ * AssignmentMissing on a mismatch -- the Rust, C++ and Python create_proof bindings do. */
+zg16_status zg16_r1cs_shape(const zg16_r1cs* r1cs, size_t* n_rows, size_t* n_inputs, size_t* n_aux);
 
 /* ---- resident keys and circuits between calls ----------------------------------------------
  * The reference's callers cannot hold a device handle: `zvm prove` reads the key and proves once per process
@@ -150,8 +157,9 @@ zg16_status zg16_r1cs_density(const zg16_r1cs* r1cs, size_t* a_aux, size_t* b_in
  * zg16_default_ctx: one context per GPU, created on first use, alive until zg16_shutdown or the end of the process
  * (do not pass it to zg16_ctx_destroy while others may still ask for it).
  * zg16_pk_cached: the resident handle of the key `view` shows, uploaded (unsharded) on first sight.  A key is
- * recognised by its vector lengths, its verifying-key points and 1024 evenly spaced points of every query; with
- * `full_digest` every point is read instead.  *was_cached (may be NULL) tells whether the upload was skipped.
+ * recognised by its vector lengths, its verifying-key points, 1024 evenly spaced points of every query and a
+ * position-weighted sum and an xor over every word of every query (memory-bound: milliseconds); with `full_digest`
+ * every byte goes through the hash instead.  *was_cached (may be NULL) tells whether the upload was skipped.
  * zg16_r1cs_cached: the same for constraint matrices.  The structure of a circuit does not depend on its inputs,
  * so a caller that can name it -- `circuit_id`, any bytes, e.g. a digest of the bytecode and the method name
  * (the synthesis-side cost: zinc-vm/src/constraint_systems/dedup.rs:30-69, logging.rs:99-111) -- calls with
@@ -171,8 +179,13 @@ void        zg16_shutdown(void);
 zg16_status zg16_pk_cached(zg16_ctx* ctx, const zg16_pk_view* view, int full_digest, zg16_pk** out,
                            int* was_cached);
 /* 1 when `pk` is a key handle this context's cache still holds (and marks it used), else 0: lets a host that
- * remembers which of its key objects maps to which handle skip building a view for zg16_pk_cached. */
-int         zg16_pk_cache_holds(zg16_ctx* ctx, const zg16_pk* pk);
+ * remembers which of its key objects maps to which handle skip building a view for zg16_pk_cached.  `id` is what
+ * zg16_pk_id returned for the handle when it was handed out -- a serial number no later handle of the process
+ * repeats.  The address alone does not identify a key: once the cache has evicted it, a newer key can be allocated
+ * at the same address, and a host thread that still remembers the old mapping would prove with the wrong tables.
+ * `pk` itself is never dereferenced here, so a stale address is safe to ask about. */
+uint64_t    zg16_pk_id(const zg16_pk* pk);
+int         zg16_pk_cache_holds(zg16_ctx* ctx, const zg16_pk* pk, uint64_t id);
 zg16_status zg16_r1cs_cached(zg16_ctx* ctx, const uint8_t* circuit_id, size_t circuit_id_len,
                              const zg16_r1cs_view* view, zg16_r1cs** out, int* was_cached);
 zg16_status zg16_cache_clear(zg16_ctx* ctx);

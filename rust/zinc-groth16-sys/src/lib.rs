@@ -61,7 +61,11 @@ extern "C" {
     pub fn zg16_pk_cached(ctx: *mut zg16_ctx, view: *const zg16_pk_view, full_digest: c_int, out: *mut *mut zg16_pk, was_cached: *mut c_int) -> c_int;
     /// bellman `verify_proof` (zinc-vm/src/core/facade.rs:32-38); host arithmetic, no context.
     pub fn zg16_verify_proof(vk: *const zg16_vk_view, proof: *const zg16_proof, public_inputs: *const u64, n_inputs: usize, accepted: *mut c_int) -> c_int;
-    pub fn zg16_pk_cache_holds(ctx: *mut zg16_ctx, pk: *const zg16_pk) -> c_int;
+    /// A serial number no later key handle of the process repeats; `zg16_pk_cache_holds` wants it beside the address.
+    pub fn zg16_pk_id(pk: *const zg16_pk) -> u64;
+    pub fn zg16_pk_cache_holds(ctx: *mut zg16_ctx, pk: *const zg16_pk, id: u64) -> c_int;
+    /// The shape the resident matrices were uploaded with (any pointer may be null).
+    pub fn zg16_r1cs_shape(r: *const zg16_r1cs, n_rows: *mut usize, n_inputs: *mut usize, n_aux: *mut usize) -> c_int;
     pub fn zg16_r1cs_cached(ctx: *mut zg16_ctx, circuit_id: *const u8, circuit_id_len: usize, view: *const zg16_r1cs_view,
                             out: *mut *mut zg16_r1cs, was_cached: *mut c_int) -> c_int;
 }
@@ -138,20 +142,32 @@ struct KeyMemo {
     h: std::sync::Arc<Vec<G1Affine>>, l: std::sync::Arc<Vec<G1Affine>>, a: std::sync::Arc<Vec<G1Affine>>,
     b_g1: std::sync::Arc<Vec<G1Affine>>, b_g2: std::sync::Arc<Vec<G2Affine>>,
     pk: usize, // *mut zg16_pk owned by the library's cache
+    id: u64,   // zg16_pk_id(pk) when it was handed out: the address alone may since belong to another key
 }
-thread_local! { static KEY_MEMO: std::cell::RefCell<Vec<KeyMemo>> = std::cell::RefCell::new(Vec::new()); }
+lazy_static::lazy_static! {
+    /// One memo for the whole process (zinc-tester proves on a rayon pool: a per-thread memo would convert every
+    /// key once per thread, and a thread's stale entry could outlive the key it names).  Only touched under
+    /// `PROVE_LOCK`.  `lazy_static!` because the reference builds with rust:1.47 (docker/Dockerfile:1), where
+    /// `Mutex::new` is not yet a const fn; zinc-vm already depends on the crate.
+    static ref KEY_MEMO: std::sync::Mutex<Vec<KeyMemo>> = std::sync::Mutex::new(Vec::new());
+    static ref PROVE_LOCK: std::sync::Mutex<()> = std::sync::Mutex::new(());
+}
 
 /// The resident handle of `params` on `ctx`: converted and handed to `zg16_pk_cached` the first time this set of
 /// `Arc`s is seen, looked up by address afterwards (no conversion, no upload).
 unsafe fn resident_key(ctx: *mut zg16_ctx, params: &Parameters<Bn256>) -> Result<*mut zg16_pk, c_int> {
     use std::sync::Arc;
-    let known = KEY_MEMO.with(|m| m.borrow().iter().find(|e|
+    let mut memo = KEY_MEMO.lock().unwrap_or_else(|poisoned| poisoned.into_inner());
+    let known = memo.iter().find(|e|
         Arc::ptr_eq(&e.h, &params.h) && Arc::ptr_eq(&e.l, &params.l) && Arc::ptr_eq(&e.a, &params.a) &&
-        Arc::ptr_eq(&e.b_g1, &params.b_g1) && Arc::ptr_eq(&e.b_g2, &params.b_g2)).map(|e| e.pk));
-    if let Some(pk) = known {
-        // the library may have evicted the key since; only a handle it still holds is used without a view
-        if zg16_pk_cache_holds(ctx, pk as *const zg16_pk) != 0 { return Ok(pk as *mut zg16_pk); }
+        Arc::ptr_eq(&e.b_g1, &params.b_g1) && Arc::ptr_eq(&e.b_g2, &params.b_g2)).map(|e| (e.pk, e.id));
+    if let Some((pk, id)) = known {
+        // the library may have evicted the key since, and handed its address to a newer one: only a handle it
+        // still holds under the same serial number is used without a view
+        if zg16_pk_cache_holds(ctx, pk as *const zg16_pk, id) != 0 { return Ok(pk as *mut zg16_pk); }
     }
+    // entries whose key the library no longer holds are of no use to anyone
+    memo.retain(|e| zg16_pk_cache_holds(ctx, e.pk as *const zg16_pk, e.id) != 0);
     let conv1 = |v: &Vec<G1Affine>| v.iter().map(g1).collect::<Vec<_>>();
     let (h, l, a, b1) = (conv1(&params.h), conv1(&params.l), conv1(&params.a), conv1(&params.b_g1));
     let b2: Vec<[u64; 16]> = params.b_g2.iter().map(g2).collect();
@@ -164,18 +180,12 @@ unsafe fn resident_key(ctx: *mut zg16_ctx, params: &Parameters<Bn256>) -> Result
     let mut hit: c_int = 0;
     let st = zg16_pk_cached(ctx, &pkv, 0, &mut pk, &mut hit);
     if st != 0 { return Err(st); }
-    KEY_MEMO.with(|m| {
-        let mut m = m.borrow_mut();
-        m.retain(|e| e.pk != pk as usize);
-        m.push(KeyMemo { h: params.h.clone(), l: params.l.clone(), a: params.a.clone(), b_g1: params.b_g1.clone(), b_g2: params.b_g2.clone(), pk: pk as usize });
-        if m.len() > 4 { m.remove(0); }
-    });
+    memo.retain(|e| e.pk != pk as usize);
+    memo.push(KeyMemo { h: params.h.clone(), l: params.l.clone(), a: params.a.clone(), b_g1: params.b_g1.clone(), b_g2: params.b_g2.clone(),
+                        pk: pk as usize, id: zg16_pk_id(pk) });
+    if memo.len() > 8 { memo.remove(0); }
     Ok(pk)
 }
-
-/// (`Mutex::new` in a static needs Rust 1.63; with an older toolchain wrap it in `lazy_static!`, which zinc-vm
-/// already depends on.)
-static PROVE_LOCK: std::sync::Mutex<()> = std::sync::Mutex::new(());
 
 /// Same signature shape and semantics as bellman's `create_proof`, plus `circuit_id`: bytes that name the circuit
 /// (e.g. a digest of the bytecode and the method name; its structure does not depend on the inputs).  Once the
@@ -208,6 +218,12 @@ pub fn create_proof_named<C: Circuit<Bn256>>(circuit: C, params: &Parameters<Bn2
             let st = zg16_r1cs_cached(ctx, idp, idl, &rv, &mut mat, &mut hit);
             if st != 0 { return Err(status_to_error(st)); }
         }
+        // zg16_prove reads as many witness elements as the resident circuit has variables: an id reused for a
+        // circuit of another shape fails here instead of reading past the witness buffers
+        let (mut n_in, mut n_aux) = (0usize, 0usize);
+        let st = zg16_r1cs_shape(mat, std::ptr::null_mut(), &mut n_in, &mut n_aux);
+        if st != 0 { return Err(status_to_error(st)); }
+        if n_in != cs.z_in.len() || n_aux != cs.z_aux.len() { return Err(SynthesisError::AssignmentMissing); }
         let mut out = std::mem::zeroed::<zg16_proof>();
         let st = zg16_prove(ctx, pk, mat, cs.z_in.as_ptr() as *const c_void, cs.z_aux.as_ptr() as *const c_void, 0,
                             &r as *const Fr as *const u64, &s as *const Fr as *const u64, &mut out);

@@ -438,7 +438,9 @@ def test_key_file_decoded_on_gpu(gpu_ctx, idx):
     mat = pa.r1cs().upload(gpu_ctx)
     zi, za = pa.witness()
     rs = ints_to_mont([int(fx["r"], 16), int(fx["s"], 16)], R_MOD)
-    for checked in (True, False):
+    # checked = True: subgroup membership of every b_g2 point by psi(P) = [6x^2] P; 2: by the plain r P = O (the
+    # slower form kept as its checker) -- the two accept the same points
+    for checked in (True, 2, False):
         dev = DeviceKey.from_bytes(gpu_ctx, data, checked=checked)
         assert prove_recorded(gpu_ctx, dev, mat, zi, za, rs[0], rs[1]).as_tuple() == fixture_proof(fx)
         dev.free()
@@ -470,8 +472,14 @@ def test_key_file_decoded_on_gpu(gpu_ctx, idx):
             break
         x = (x[0] + 1, 1)
     off = len(data) - 128 * len(key.b_g2)
+    assert not codec._g2_times_order_is_identity((x, y))
     bad = bytearray(data); bad[off:off + 128] = codec.g2_write((x, y), False)
-    assert rejected(bad)
+    assert rejected(bad) and rejected(bad, checked=2)
+    DeviceKey.from_bytes(gpu_ctx, bytes(bad), checked=False).free()
+    # the same point as gamma_g2: verifying-key points are checked on the host, with the same two tests
+    g0 = 64 * 2 + 128
+    bad = bytearray(data); bad[g0:g0 + 128] = codec.g2_write((x, y), False)
+    assert rejected(bad) and rejected(bad, checked=2) and rejected(bad, checked=False)
     # alpha_g1 (a verifying-key point) may be anything on the curve, but not off it -- whatever `checked` says:
     # upstream's VerifyingKey::read validates its points unconditionally
     bad = bytearray(data); bad[63] ^= 1

@@ -62,6 +62,17 @@ def test_recorder_builds_canonical_csr():
     assert any(c & AUX for c in cols) and all((c & ~AUX) < max(circ.n_aux, circ.n_in) for c in cols)
 
 
+def off_subgroup_twist_point():
+    """A point of the twist y^2 = x^3 + 3 / (9 + u) whose order is not r (the twist's cofactor is 2q - r)."""
+    x = (5, 1)
+    while True:
+        rhs = codec._fq2_mul(codec._fq2_mul(x, x), x)
+        y = codec._fq2_sqrt(((rhs[0] + codec.B_G2[0]) % codec.Q_MOD, (rhs[1] + codec.B_G2[1]) % codec.Q_MOD))
+        if y is not None and not codec._g2_times_order_is_identity((x, y)):
+            return x, y
+        x = (x[0] + 1, 1)
+
+
 @pytest.mark.parametrize("idx", [1, 2, 3])
 def test_proof_codec_golden(idx):
     fx = golden("prove_tiny_%d.json" % idx)
@@ -96,17 +107,20 @@ def test_params_codec_roundtrip_and_checks():
     ba[ic0:ic0 + 64] = bytes([0x40]) + bytes(63)
     with pytest.raises(codec.DecodeError):
         codec.params_read(bytes(ba), checked=False)
-    # a twist point outside the prime-order subgroup is refused
-    x = (5, 1)
-    while True:
-        rhs = codec._fq2_mul(codec._fq2_mul(x, x), x)
-        y = codec._fq2_sqrt(((rhs[0] + codec.B_G2[0]) % codec.Q_MOD, (rhs[1] + codec.B_G2[1]) % codec.Q_MOD))
-        if y is not None:
-            break
-        x = (x[0] + 1, 1)
+    # a twist point outside the prime-order subgroup is refused, in the uncompressed form of a key file and in the
+    # compressed form of a proof's B (pairing_ce's into_affine() checks both)
+    x, y = off_subgroup_twist_point()
     with pytest.raises(codec.DecodeError):
         codec.g2_read(codec.g2_write((x, y), False), False, True)
     assert codec.g2_read(codec.g2_write((x, y), False), False, False) == (x, y)
+    with pytest.raises(codec.DecodeError):
+        codec.g2_read(codec.g2_write((x, y), True), True, True)
+    a, _, c = fixture_proof(golden("prove_tiny_1.json"))
+    with pytest.raises(codec.DecodeError):
+        codec.proof_read(codec.proof_write((a, (x, y), c)))
+    # bellman's Proof::read refuses the point at infinity in any of the three places
+    with pytest.raises(codec.DecodeError):
+        codec.proof_read(codec.proof_write((a, None, c)))
     # infinity in a query vector is rejected when checked, accepted otherwise
     key.h[0] = None
     bad = codec.params_write(key)
@@ -327,6 +341,28 @@ def test_verify_proof_golden(idx):
     with pytest.raises(SynthesisError) as e:
         verify_proof(VK, raw, public + [1])
     assert e.value.status_name == "MalformedKey"
+    # B is the one untrusted G2 point: on the twist but outside the prime-order subgroup, off the twist, and limbs
+    # that are not a residue below q (in A, B or C) are all "not a proof" -- bellman's Proof::read refuses them
+    bad = zlib.Proof.from_buffer_copy(bytes(raw))
+    bad.b[:] = [int(x) for x in g2_to_mont([off_subgroup_twist_point()])[0]]
+    assert not verify_proof(VK, bad, public)
+    bad = zlib.Proof.from_buffer_copy(bytes(raw))
+    bad.b[5] ^= 1
+    assert not verify_proof(VK, bad, public)
+    from zinc_amd.fields import Q_MOD
+    for field, limb0 in (("a", 0), ("a", 4), ("b", 8), ("c", 4)):
+        bad = zlib.Proof.from_buffer_copy(bytes(raw))
+        arr = getattr(bad, field)
+        val = sum(int(arr[limb0 + i]) << (64 * i) for i in range(4)) + Q_MOD   # the same residue, not canonical
+        if val >> 256:
+            continue
+        for i in range(4):
+            arr[limb0 + i] = (val >> (64 * i)) & ((1 << 64) - 1)
+        assert not verify_proof(VK, bad, public)
+    # the identity in B (an in-memory proof may hold it; e(A, O) = 1): handled, not a crash
+    bad = zlib.Proof.from_buffer_copy(bytes(raw))
+    bad.b[:] = [0] * 16
+    assert not verify_proof(VK, bad, public)
 
 
 def test_verify_fast_pairing_equals_plain_pairing():

@@ -181,3 +181,89 @@ def test_table_memory_budget_falls_back_to_fewer_windows(gpu_ctx, monkeypatch, b
         assert np.array_equal(np.frombuffer(bytes(g), dtype=np.uint64), w)
     key.free()
     mat.free()
+
+
+def test_stale_key_address_is_not_taken_for_a_resident_key(monkeypatch):
+    """A host that remembers (address, serial number) of the handle a key got: after the cache has evicted the key
+    the pair is refused, even when a newer key has been allocated at the same address -- the address alone would
+    pick the wrong key's tables."""
+    import zinc_amd
+    from zinc_amd.groth16 import Parameters
+    ctx = zinc_amd.Context(0)
+    monkeypatch.setenv("ZG16_CACHE_KEYS", "1")
+    L = ctx._lib
+    fxs = [golden("prove_tiny_%d.json" % i) for i in (1, 2, 3)]
+    params = [Parameters.from_points(FixtureKey(fx)) for fx in fxs]
+    seen = []
+    for p in params * 3:                       # every call evicts the previous key
+        k, hit = p.cached(ctx)
+        assert not hit
+        kid = L.zg16_pk_id(k.handle)
+        assert kid and all(kid != i for _, i in seen), "a serial number was handed out twice"
+        assert L.zg16_pk_cache_holds(ctx.handle, k.handle, kid) == 1
+        assert L.zg16_pk_cache_holds(ctx.handle, k.handle, kid + 1) == 0
+        for addr, old in seen:                 # every earlier handle is gone, whatever lives at its address now
+            assert L.zg16_pk_cache_holds(ctx.handle, addr, old) == 0
+        seen.append((k.handle.value, kid))
+    ctx.close()
+
+
+def test_same_shape_keys_under_one_setup_are_told_apart(gpu_ctx):
+    """Two circuits of the same shape that differ in a few rows, keys from the same toxic waste: vk and h are the
+    same and most l / a / b points too, so a digest of sampled points can take one for the other.  The digest folds
+    every word of every query: each key gets its own resident handle and its own (correct) proof."""
+    from zinc_amd import workload
+    from zinc_amd.groth16 import prove_recorded, R1CS
+    from zinc_amd.fields import mont_to_ints
+    from oracle import cpu_binding as cb
+    toxic = dict(k1=5, k2=7, alpha=11, beta=13, gamma=17, delta=19, tau=41)
+    circ = workload.SyntheticCircuit(1 << 12, seed=(2, 7, 1, 8))
+    r1 = circ.r1cs()
+    zi, za = circ.witness()
+    # the twin: one coefficient of one A row doubled (and its C side is irrelevant to key generation)
+    mats = [(rp.copy(), col.copy(), co.copy()) for rp, col, co in r1.mats]
+    rp, col, co = mats[0]
+    row = 2049
+    while rp[row + 1] == rp[row]:
+        row += 1
+    e = int(rp[row])
+    v = mont_to_ints(co[e:e + 1], R_MOD)[0]
+    co[e] = ints_to_mont([2 * v % R_MOD], R_MOD)[0]
+    r2 = R1CS(r1.n_inputs, r1.n_aux, mats)
+    p1 = workload.generate_parameters(gpu_ctx, r1, toxic)
+    p2 = workload.generate_parameters(gpu_ctx, r2, toxic)
+    assert np.array_equal(p1.h, p2.h) and p1.a.shape == p2.a.shape and not np.array_equal(p1.a, p2.a)
+    assert int((p1.a != p2.a).any(axis=1).sum()) <= 2
+    gpu_ctx.cache_clear()
+    k1, hit1 = p1.cached(gpu_ctx)
+    k2, hit2 = p2.cached(gpu_ctx)
+    assert not hit1 and not hit2 and k1.handle.value != k2.handle.value
+    assert p1.cached(gpu_ctx)[1] and p2.cached(gpu_ctx)[1]
+    # the first circuit's witness proves under its own key, bit for bit
+    rs = ints_to_mont([0x77, 0x99], R_MOD)
+    mat = r1.upload(gpu_ctx)
+    got = prove_recorded(gpu_ctx, k1, mat, zi, za, rs[0], rs[1])
+    st, want, _ = cb.prove(p1, r1, zi, za, rs[0], rs[1], threads=4)
+    assert st == 0
+    for g, w in zip((got.raw.a, got.raw.b, got.raw.c), want):
+        assert np.array_equal(np.frombuffer(bytes(g), dtype=np.uint64), w)
+    mat.free()
+    gpu_ctx.cache_clear()
+
+
+def test_circuit_id_reused_for_another_shape_is_refused():
+    """A circuit id that is already resident, handed a circuit with another number of variables: the binding
+    compares the witness lengths with zg16_r1cs_shape and reports AssignmentMissing instead of letting zg16_prove
+    read past the witness buffers."""
+    import zinc_amd
+    from zinc_amd.groth16 import Parameters, create_proof, SynthesisError
+    ctx = zinc_amd.Context(0)
+    fx1, fx3 = golden("prove_tiny_1.json"), golden("prove_tiny_3.json")
+    p1, p3 = Parameters.from_points(FixtureKey(fx1)), Parameters.from_points(FixtureKey(fx3))
+    assert create_proof(FixtureCircuit(fx1), p1, 3, 5, ctx, circuit_id=b"one-name").as_tuple()
+    c1, c3 = FixtureCircuit(fx1), FixtureCircuit(fx3)
+    assert (len(c1.z_in), len(c1.z_aux)) != (len(c3.z_in), len(c3.z_aux))
+    with pytest.raises(SynthesisError) as e:
+        create_proof(c3, p3, 3, 5, ctx, circuit_id=b"one-name")
+    assert e.value.status_name == "AssignmentMissing"
+    ctx.close()

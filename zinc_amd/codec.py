@@ -185,6 +185,10 @@ def g2_read(buf, compressed, checked=True):
         ny = ((-y[0]) % Q_MOD, (-y[1]) % Q_MOD)
         if _fq2_gt(y, ny) != bool(flags & 0x80):
             y = ny
+        # pairing_ce's G2Compressed::into_affine refuses a point outside the prime-order subgroup, so bellman's
+        # Proof::read never hands one to the verifier
+        if checked and not _g2_times_order_is_identity((x, y)):
+            raise DecodeError("point is not in the prime-order subgroup")
         return (x, y)
     y = (_int(buf[96:128]), _int(buf[64:96]))
     if checked:
@@ -205,7 +209,10 @@ def proof_write(proof):
 def proof_read(data):
     if len(data) != 128:
         raise DecodeError("a BN256 Groth16 proof is 128 bytes")
-    return (g1_read(data[:32], True), g2_read(data[32:96], True), g1_read(data[96:], True))
+    proof = (g1_read(data[:32], True), g2_read(data[32:96], True), g1_read(data[96:], True))
+    if any(p is None for p in proof):  # bellman's Proof::read: "point at infinity" is InvalidData
+        raise DecodeError("point at infinity in a proof")
+    return proof
 
 
 class KeyPoints:

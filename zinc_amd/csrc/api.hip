@@ -476,6 +476,14 @@ zg16_status zg16_r1cs_density(const zg16_r1cs* r, size_t* a_aux, size_t* b_input
   return ZG16_OK;
 }
 
+zg16_status zg16_r1cs_shape(const zg16_r1cs* r, size_t* n_rows, size_t* n_inputs, size_t* n_aux) {
+  if (!r) return ZG16_ERR_INVALID_ARGUMENT;
+  if (n_rows) *n_rows = r->n_rows;
+  if (n_inputs) *n_inputs = r->n_in;
+  if (n_aux) *n_aux = r->n_aux;
+  return ZG16_OK;
+}
+
 // ---------------------------------------------------------------------------------------- prove
 }  // extern "C"
 

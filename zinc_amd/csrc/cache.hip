@@ -80,11 +80,33 @@ static size_t env_limit(const char* name, size_t dflt) {
   return v < 1 ? 1 : (size_t)v;
 }
 
-// What identifies a key: the lengths of its vectors, its verifying-key points and SAMPLES evenly spaced points of
-// every query (all of them when `full`).  Two setups of one circuit differ in every point and two circuits under
-// one setup differ in their l, a and b points wherever their matrices differ, so the samples tell apart every pair
-// of keys a prover meets; `full` reads every byte for callers that want no assumption at all.
+// What identifies a key: the lengths of its vectors, its verifying-key points, SAMPLES evenly spaced points of
+// every query and a position-weighted sum and an xor over ALL of its words (every byte through the hash when
+// `full`).  Two setups of one circuit differ in every point; two circuits under one setup differ in their l, a and
+// b points only where their matrices differ, which the samples can miss and the folds do not.
 static constexpr size_t SAMPLES = 1024;
+// Sum and xor of every 8-byte word of a query (order-free, so the pieces can be folded on several host threads):
+// two keys of the same shape under the same setup that differ in a handful of points -- two circuits that differ
+// in a few rows share every sampled point with high probability -- still get different digests.  Memory-bound:
+// the 0.4 GB key of a 2^20-row circuit folds in a few milliseconds.
+static void fold_words(const void* p, size_t bytes, uint64_t* sum, uint64_t* x) {
+  const size_t words = bytes / 8;
+  const uint64_t* w = (const uint64_t*)p;
+  std::mutex mu;
+  uint64_t s_all = 0, x_all = 0;
+  host_parallel(words, [&](size_t lo, size_t hi) {
+    uint64_t s0 = 0, x0 = 0;
+    for (size_t i = lo; i < hi; i++) {
+      s0 += w[i] * (2 * (uint64_t)(i & 0xffff) + 1);  // position-weighted (mod 2^16), so swapped points differ too
+      x0 ^= w[i];
+    }
+    std::lock_guard<std::mutex> lock(mu);
+    s_all += s0;
+    x_all ^= x0;
+  });
+  *sum = s_all;
+  *x = x_all;
+}
 static Digest key_digest(const zg16_pk_view* v, bool full) {
   Hasher h;
   h.bytes(v->alpha_g1, 64); h.bytes(v->beta_g1, 64); h.bytes(v->beta_g2, 128);
@@ -99,6 +121,10 @@ static Digest key_digest(const zg16_pk_view* v, bool full) {
       h.bytes(base, x.n * x.width);
     } else {
       for (size_t k = 0; k < SAMPLES; k++) h.bytes(base + ((x.n - 1) * k / (SAMPLES - 1)) * x.width, x.width);
+      uint64_t sum, xr;
+      fold_words(base, x.n * x.width, &sum, &xr);
+      h.word(sum);
+      h.word(xr);
     }
   }
   return h.done();
@@ -170,19 +196,27 @@ extern "C" {
 
 zg16_status zg16_default_ctx(int device_id, zg16_ctx** out) {
   if (!out) return ZG16_ERR_INVALID_ARGUMENT;
-  std::lock_guard<std::mutex> lock(g_default_mutex);
-  auto it = g_default_ctx.find(device_id);
-  if (it != g_default_ctx.end()) {
-    *out = it->second;
-    return ZG16_OK;
+  *out = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_default_mutex);
+    auto it = g_default_ctx.find(device_id);
+    if (it != g_default_ctx.end()) {
+      *out = it->second;
+      return ZG16_OK;
+    }
   }
+  // Created outside the lock: zg16_ctx_create's failure path goes through zg16_ctx_destroy, which takes the lock
+  // itself (default_ctx_forget).  Two threads that race here both create one; the loser's is destroyed.
   zg16_ctx* ctx = nullptr;
   const zg16_status st = zg16_ctx_create(device_id, &ctx);
-  if (st != ZG16_OK) {
-    *out = nullptr;
-    return st;
+  if (st != ZG16_OK) return st;
+  zg16_ctx* mine = ctx;
+  {
+    std::lock_guard<std::mutex> lock(g_default_mutex);
+    auto ins = g_default_ctx.emplace(device_id, ctx);
+    ctx = ins.first->second;
   }
-  g_default_ctx[device_id] = ctx;
+  if (ctx != mine) zg16_ctx_destroy(mine);
   *out = ctx;
   return ZG16_OK;
 }
@@ -229,10 +263,14 @@ zg16_status zg16_pk_cached(zg16_ctx* ctx, const zg16_pk_view* view, int full_dig
   return ZG16_OK;
 }
 
-int zg16_pk_cache_holds(zg16_ctx* ctx, const zg16_pk* pk) {
-  if (!ctx || !pk || !ctx->cache) return 0;
+uint64_t zg16_pk_id(const zg16_pk* pk) { return pk ? pk->id : 0; }
+
+int zg16_pk_cache_holds(zg16_ctx* ctx, const zg16_pk* pk, uint64_t id) {
+  if (!ctx || !pk || !id || !ctx->cache) return 0;
+  // `pk` may be a stale address (its key evicted, the address reused by a newer key): only the cache's own, live
+  // entries are dereferenced, and the address counts only together with the serial number it had when handed out
   for (auto& e : ctx->cache->keys)
-    if (e.pk == pk) {
+    if (e.pk == pk && e.pk->id == id) {
       e.last_use = ++ctx->cache->clock;
       ctx->cache->key_hits++;
       return 1;

@@ -245,4 +245,63 @@ using G2Affine = Affine<Fq2>;
 using G1XYZZ = XYZZ<Fq>;
 using G2XYZZ = XYZZ<Fq2>;
 
+// ---- membership of the prime-order subgroup of the twist (what pairing_ce's `into_affine()` checks) ----
+// psi = untwist, q-power Frobenius, twist:  psi(x, y) = (conj(x) * xi^((q-1)/3), conj(y) * xi^((q-1)/2)), xi = 9 + u.
+// On the whole twist curve psi^2 - t psi + q = 0 with t = q + 1 - r = 6 x^2 + 1 (x the BN parameter), so a point with
+// psi(P) = [6 x^2] P satisfies ((6x^2)^2 - (6x^2 + 1) 6x^2 + q) P = (q - 6x^2) P = r P = O; and on the order-r
+// subgroup psi IS multiplication by q = 6 x^2 (mod r).  The test "on the curve and psi(P) = [6x^2] P" therefore
+// accepts exactly the points that "on the curve and r P = O" accepts, with a 127-bit scalar instead of a 254-bit one.
+struct G2SubgroupConsts {
+  Fq2 curve_b;  // 3 / xi
+  Fq2 psi_x;    // xi^((q - 1) / 3)
+  Fq2 psi_y;    // xi^((q - 1) / 2)
+};
+
+ZG_HD bool g2_in_subgroup(const Affine<Fq2>& p, const G2SubgroupConsts& k) {
+  if (p.is_inf()) return true;
+  // 6 x^2 = 0x6f4d8248eeb859fbf83e9682e87cfd46, x = 4965661367192848881
+  const uint32_t e[4] = {0xe87cfd46u, 0xf83e9682u, 0xeeb859fbu, 0x6f4d8248u};
+  XYZZ<Fq2> acc = XYZZ<Fq2>::inf();
+  for (int i = 3; i >= 0; i--)
+    for (int b = 31; b >= 0; b--) {
+      acc = dbl(acc);
+      if ((e[i] >> b) & 1) add_mixed(acc, p);
+    }
+  if (acc.is_inf()) return false;  // psi(P) is a finite point
+  const Fq2 px = mul(Fq2{p.x.c0, neg(p.x.c1)}, k.psi_x), py = mul(Fq2{p.y.c0, neg(p.y.c1)}, k.psi_y);
+  return mul(px, acc.zz) == acc.x && mul(py, acc.zzz) == acc.y;
+}
+
+// Host: the three constants, computed once per process.
+inline const G2SubgroupConsts& g2_subgroup_consts() {
+  static const G2SubgroupConsts consts = [] {
+    const Fq2 xi = {from_u64<FqParams>(9), Fq::one()};
+    const Fq2 three = {from_u64<FqParams>(3), Fq::zero()};
+    auto xi_pow_q_minus_1_over = [&](uint64_t d) {
+      uint32_t e[8];
+      for (int i = 0; i < 8; i++) e[i] = FqParams::mod(i);
+      e[0] -= 1;  // q is odd
+      uint64_t rem = 0;
+      for (int i = 7; i >= 0; i--) {  // exact: q = 1 (mod 6)
+        const uint64_t cur = (rem << 32) | e[i];
+        e[i] = (uint32_t)(cur / d);
+        rem = cur % d;
+      }
+      Fq2 g = Fq2::one();
+      for (int i = 7; i >= 0; i--)
+        for (int b = 31; b >= 0; b--) {
+          g = sqr(g);
+          if ((e[i] >> b) & 1) g = mul(g, xi);
+        }
+      return g;
+    };
+    G2SubgroupConsts c;
+    c.curve_b = mul(three, inv(xi));
+    c.psi_x = xi_pow_q_minus_1_over(3);
+    c.psi_y = xi_pow_q_minus_1_over(2);
+    return c;
+  }();
+  return consts;
+}
+
 }  // namespace zg

@@ -279,6 +279,9 @@ ZG_HD Fp<P> pow_limbs(const Fp<P>& a, const uint32_t* e, int nlimbs) {
   return r;
 }
 
+template <class P>
+ZG_HD bool is_canonical(const uint32_t* a);
+
 #if !defined(__HIP_DEVICE_COMPILE__)
 // Host only: a^-1 by the binary extended Euclidean algorithm on the Montgomery representation read as an integer
 // (shifts, additions and subtractions of 256-bit integers: about a microsecond, against ~380 field products for
@@ -330,6 +333,9 @@ template <class P>
 inline Fp<P> inv_host(const Fp<P>& a) {
   using namespace host_inv;
   if (a.is_zero()) return a;  // as the power does
+  // limbs that are not a residue below p (never produced by this library's arithmetic; a caller's raw bytes can
+  // be): the loop below ends only for inputs coprime to p, and u = p is not -- answer as for zero
+  if (!is_canonical<P>(a.v)) return Fp<P>::zero();
   U256 u, v, x1 = {{1, 0, 0, 0}}, x2 = {{0, 0, 0, 0}};
   for (int i = 0; i < 4; i++) {
     u.w[i] = (uint64_t)a.v[2 * i] | ((uint64_t)a.v[2 * i + 1] << 32);

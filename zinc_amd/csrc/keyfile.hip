@@ -5,7 +5,8 @@
 // pairing_ce encoding, checked to be on the curve and in the prime-order subgroup, and the query
 // vectors may not contain the point at infinity.  On one host thread that is minutes for a 2^24-row
 // key; here the byte ranges go to the GPU as they are and one kernel decodes, converts to Montgomery
-// form and checks each point (G2 includes the multiplication by r).
+// form and checks each point (G2: on the twist and psi(P) = [6x^2] P, which holds exactly when r P = O -- see
+// g2_in_subgroup in curve.hpp; `checked` = 2 runs the plain multiplication by r instead, kept as its checker).
 //
 // Layout (bellman_ce 0.3.0 / pairing_ce 0.17.0, not part of the reference tree):
 //   alpha_g1 beta_g1 (G1) beta_g2 gamma_g2 (G2) delta_g1 (G1) delta_g2 (G2) | u32-BE n, ic[n] (G1)
@@ -63,7 +64,7 @@ ZG_HD uint32_t decode_g1(const uint8_t* b, bool checked, bool allow_inf, Affine<
 // r, the group order, little-endian words
 ZG_HD uint32_t order_word(int i) { return FrParams::mod(i); }
 
-ZG_HD uint32_t decode_g2(const uint8_t* b, bool checked, bool allow_inf, const Fq2& curve_b, Affine<Fq2>* out) {
+ZG_HD uint32_t decode_g2(const uint8_t* b, int checked, bool allow_inf, const G2SubgroupConsts& k, Affine<Fq2>* out) {
   *out = Affine<Fq2>::inf();
   if (b[0] & 0x80) return DEC_ENCODING;
   if (b[0] & 0x40) {
@@ -75,10 +76,14 @@ ZG_HD uint32_t decode_g2(const uint8_t* b, bool checked, bool allow_inf, const F
       !read_fq(b + 96, false, &p.y.c0))
     return DEC_ENCODING;
   if (checked) {
-    if (!on_curve(p, curve_b)) return DEC_NOT_ON_CURVE;
-    uint32_t r[8];
-    for (int i = 0; i < 8; i++) r[i] = order_word(i);
-    if (!scalar_mul(XYZZ<Fq2>::from_affine(p), r).is_inf()) return DEC_NOT_IN_SUBGROUP;
+    if (!on_curve(p, k.curve_b)) return DEC_NOT_ON_CURVE;
+    if (checked == 2) {
+      uint32_t r[8];
+      for (int i = 0; i < 8; i++) r[i] = order_word(i);
+      if (!scalar_mul(XYZZ<Fq2>::from_affine(p), r).is_inf()) return DEC_NOT_IN_SUBGROUP;
+    } else if (!g2_in_subgroup(p, k)) {
+      return DEC_NOT_IN_SUBGROUP;
+    }
   }
   *out = p;
   return DEC_OK;
@@ -94,20 +99,14 @@ __global__ __launch_bounds__(256) void k_decode_g1(const uint8_t* __restrict__ s
   if (e) atomicMax(err, e);
 }
 
-__global__ __launch_bounds__(256, 1) void k_decode_g2(const uint8_t* __restrict__ src, uint32_t n, int checked, Fq2 curve_b,
+__global__ __launch_bounds__(256, 1) void k_decode_g2(const uint8_t* __restrict__ src, uint32_t n, int checked, G2SubgroupConsts curve_b,
                                                       Affine<Fq2>* __restrict__ dst, uint32_t* __restrict__ err) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Affine<Fq2> p;
-  const uint32_t e = decode_g2(src + (size_t)i * 128, checked != 0, false, curve_b, &p);
+  const uint32_t e = decode_g2(src + (size_t)i * 128, checked, false, curve_b, &p);
   dst[i] = p;
   if (e) atomicMax(err, e);
-}
-
-static Fq2 g2_curve_b() {  // 3 / (9 + u)
-  const Fq2 xi = {from_u64<FqParams>(9), from_u64<FqParams>(1)};
-  const Fq2 three = {from_u64<FqParams>(3), Fq::zero()};
-  return mul(three, inv(xi));
 }
 
 static const char* decode_text(uint32_t e) {
@@ -151,7 +150,7 @@ static zg16_status query_tables(zg16_ctx* ctx, Affine<F>* pts, size_t count, uin
 // fill the other windows.
 template <class F>
 static zg16_status decode_query(zg16_ctx* ctx, const uint8_t* bytes, size_t lo, size_t hi, int checked, uint32_t table_c,
-                                uint32_t table_step, const Fq2& curve_b, const char* name, Affine<F>** dst,
+                                uint32_t table_step, const G2SubgroupConsts& curve_b, const char* name, Affine<F>** dst,
                                 Affine<F>** direct, bool build_tables) {
   *dst = nullptr;
   *direct = nullptr;
@@ -192,7 +191,7 @@ zg16_status zg16_pk_upload_bytes(zg16_ctx* ctx, const uint8_t* data, size_t len,
   *out = nullptr;
   if (len >= ((size_t)1 << 40)) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "key data too large");
   ZG_HIP(ctx, hipSetDevice(ctx->device));
-  const Fq2 curve_b = g2_curve_b();
+  const G2SubgroupConsts& curve_b = g2_subgroup_consts();
   Cursor cur = {data, len};
   auto eof = [&]() { return fail(ctx, ZG16_ERR_MALFORMED_KEY, "unexpected end of key data"); };
   std::unique_ptr<zg16_pk, void (*)(zg16_pk*)> pk(new zg16_pk(), zg::pk_destroy);
@@ -212,7 +211,7 @@ zg16_status zg16_pk_upload_bytes(zg16_ctx* ctx, const uint8_t* data, size_t len,
   };
   auto g2 = [&](G2Affine* dst, const char* what) -> zg16_status {
     if (!cur.take(128, &b)) return eof();
-    if ((e = decode_g2(b, true, true, curve_b, dst))) return fail(ctx, ZG16_ERR_MALFORMED_KEY, "%s: %s", what, decode_text(e));
+    if ((e = decode_g2(b, checked == 2 ? 2 : 1, true, curve_b, dst))) return fail(ctx, ZG16_ERR_MALFORMED_KEY, "%s: %s", what, decode_text(e));
     return ZG16_OK;
   };
   G2Affine gamma2;

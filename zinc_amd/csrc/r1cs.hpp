@@ -1,6 +1,7 @@
 // Device-resident constraint matrices and proving key (internal definitions of the opaque
 // handles declared in include/zinc_groth16.h).
 #pragma once
+#include <atomic>
 #include <memory>
 #include <thread>
 
@@ -58,6 +59,13 @@ void spmv_encode_coeffs(const uint64_t* coeff, size_t nnz, std::vector<uint16_t>
 
 }  // namespace zg
 
+namespace zg {
+inline uint64_t next_handle_id() {
+  static std::atomic<uint64_t> counter{0};
+  return ++counter;
+}
+}  // namespace zg
+
 struct zg16_r1cs {
   zg16_ctx* ctx = nullptr;
   bool cached = false;  // owned by the context's cache: zg16_r1cs_free leaves it alone
@@ -75,6 +83,7 @@ struct zg16_r1cs {
 struct zg16_pk {
   zg16_ctx* ctx = nullptr;
   bool cached = false;  // owned by the context's cache: zg16_pk_free leaves it alone
+  uint64_t id = zg::next_handle_id();  // serial number, never reused in a process: tells a handle from a later one at its address
   size_t device_bytes = 0;  // HBM held by the query tables
   int shard_index = 0, shard_count = 1;
   bool h_cyclic = false;  // the h query holds h[shard_index + shard_count * j] at slot j ([lo_h, hi_h) = [0, slots))

@@ -388,7 +388,13 @@ extern "C" zg16_status zg16_verify_proof(const zg16_vk_view* vk, const zg16_proo
   const G1Affine a = load_point<G1Affine>(proof->a), c = load_point<G1Affine>(proof->c), alpha = load_point<G1Affine>(vk->alpha_g1);
   const G2Affine b = load_point<G2Affine>(proof->b), beta = load_point<G2Affine>(vk->beta_g2),
                  gamma = load_point<G2Affine>(vk->gamma_g2), delta = load_point<G2Affine>(vk->delta_g2);
-  if (!on_curve_g1(a) || !on_curve_g1(c)) return ZG16_OK;  // not a proof: rejected
+  // What bellman's `Proof::read` refuses never reaches its verifier (pairing_ce's `into_affine()`: coordinates below
+  // q, on the curve, in the prime-order subgroup); a caller that hands over raw limbs gets the same answer here:
+  // not a proof, rejected.  B is the one untrusted G2 point; a Miller loop on a point outside G2 proves nothing.
+  for (const uint64_t* limbs : {proof->a, proof->a + 4, proof->c, proof->c + 4, proof->b, proof->b + 4, proof->b + 8, proof->b + 12})
+    if (!is_canonical<FqParams>((const uint32_t*)limbs)) return ZG16_OK;
+  if (!on_curve_g1(a) || !on_curve_g1(c)) return ZG16_OK;
+  if (!on_curve(b, g2_subgroup_consts().curve_b) || !g2_in_subgroup(b, g2_subgroup_consts())) return ZG16_OK;
   // e(P, Q) with either argument the identity is one: such a factor is skipped
   struct Pair {
     G2Affine q;

@@ -349,6 +349,12 @@ class DeviceR1CS:
         _check(self.ctx.handle, self.ctx._lib.zg16_r1cs_density(self.handle, C.byref(a), C.byref(bi), C.byref(ba)))
         return a.value, bi.value, ba.value
 
+    def shape(self):
+        """zg16_r1cs_shape: (n_rows, n_inputs, n_aux) the matrices were uploaded with."""
+        n, ni, na = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        _check(self.ctx.handle, self.ctx._lib.zg16_r1cs_shape(self.handle, C.byref(n), C.byref(ni), C.byref(na)))
+        return n.value, ni.value, na.value
+
     def spmv(self, z_in, z_aux):
         n = self.r1cs.n_rows
         outs = [np.zeros((n, 4), dtype=np.uint64) for _ in range(3)]
@@ -541,6 +547,12 @@ def create_proof(circuit, params, r, s, ctx=None, circuit_id=None):
     key, _ = params.cached(ctx)
     if mat is None:
         mat, _ = DeviceR1CS.cached(ctx, circuit_id, pa.r1cs())
+    # zg16_prove reads as many witness elements as the resident circuit has variables: a circuit_id reused for a
+    # circuit of another shape must fail here, not read past the buffers (bellman: AssignmentMissing)
+    _, n_in, n_aux = mat.shape()
+    if (n_in, n_aux) != (len(pa.z_in), len(pa.z_aux)):
+        raise SynthesisError(3, "the circuit resident under this id has %d inputs and %d aux variables, synthesis "
+                                "produced %d and %d" % (n_in, n_aux, len(pa.z_in), len(pa.z_aux)))
     zi, za = pa.witness()
     rs = ints_to_mont([r, s], R_MOD)
     return prove_recorded(ctx, key, mat, zi, za, rs[0], rs[1])

@@ -219,6 +219,12 @@ class Prover {
   }
   Proof prove(const ProvingAssignment& pa, const Limbs& r, const Limbs& s) {
     Proof out;
+    // zg16_prove reads as many witness elements as the resident circuit has variables: a circuit known only by its
+    // id must have the shape this synthesis produced (bellman: AssignmentMissing), or the buffers would be overrun
+    size_t n_in = 0, n_aux = 0;
+    check(zg16_r1cs_shape(r1cs_, nullptr, &n_in, &n_aux));
+    if (n_in != pa.z_in.size() || n_aux != pa.z_aux.size())
+      throw SynthesisError(ZG16_ERR_ASSIGNMENT_MISSING, "the resident circuit has another number of variables than the witness");
     check(zg16_prove(ctx_, pk_, r1cs_, (const uint64_t*)pa.z_in.data(), (const uint64_t*)pa.z_aux.data(), 0, r.data(),
                      s.data(), &out));
     return out;

@@ -99,7 +99,8 @@ SYMBOLS = [
     ("zg16_default_ctx", C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     ("zg16_shutdown", None, []),
     ("zg16_pk_cached", C.c_int, [C.c_void_p, C.POINTER(PkView), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
-    ("zg16_pk_cache_holds", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("zg16_pk_id", C.c_uint64, [C.c_void_p]),
+    ("zg16_pk_cache_holds", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     ("zg16_r1cs_cached", C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(R1csView), C.POINTER(C.c_void_p),
                                    C.POINTER(C.c_int)]),
     ("zg16_cache_clear", C.c_int, [C.c_void_p]),
@@ -107,6 +108,7 @@ SYMBOLS = [
     ("zg16_r1cs_upload", C.c_int, [C.c_void_p, C.POINTER(R1csView), C.POINTER(C.c_void_p)]),
     ("zg16_r1cs_free", None, [C.c_void_p]),
     ("zg16_r1cs_density", C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    ("zg16_r1cs_shape", C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     ("zg16_prove", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                              u64p, u64p, C.POINTER(Proof)]),
     ("zg16_prove_from_evals", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
