@@ -59,6 +59,19 @@ def parse():
     return ap.parse_args()
 
 
+def cpu_model():
+    """The host CPU's model string (/proc/cpuinfo), reported beside the core count of the CPU baseline."""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
 def cpu_baseline_leg(ctx, log_rows, dense, reuse=None):
     """Time the CPU restatement of the bellman prover on a bounded sample of the same workload and
     check that the GPU produces the identical proof for it.  The only place this file touches oracle/.
@@ -85,7 +98,8 @@ def cpu_baseline_leg(ctx, log_rows, dense, reuse=None):
         mat.free()
     same = all(np.array_equal(np.frombuffer(bytes(g), dtype=np.uint64), c)
                for g, c in zip((gpu.raw.a, gpu.raw.b, gpu.raw.c), cpu_proof))
-    return {"value": tm["total_s"], "unit": "s", "cores": threads, "kind": "port",
+    return {"value": tm["total_s"], "unit": "s", "cores": threads, "cpu_model": cpu_model(),
+            "host_cpus_online": os.cpu_count(), "kind": "port",
             "sample": "full prove of the same synthetic circuit at 2^%d rows (1/%d of the GPU workload), "
                       "restated bellman algorithms, %d threads; fft %.3fs multiexp %.3fs"
                       % (log_rows, 1, threads, tm["fft_s"], tm["multiexp_s"]),
@@ -168,13 +182,40 @@ class ProveCase:
         self.pk_view = self.params.view()
 
     def step(self):
+        return self.step_with(self.z_in_dev.data_ptr(), self.z_aux_dev.data_ptr(), 1)
+
+    def step_with(self, z_in_ptr, z_aux_ptr, on_device):
         from zinc_amd.distributed import prove_sharded
         d = self.d
         if self.sharded:
-            return self.sharded.prove(self.z_in_dev.data_ptr(), self.z_aux_dev.data_ptr(), 1, self.rs[0], self.rs[1])
-        return prove_sharded(self.ctx, self.key, self.mat, self.z_in_dev.data_ptr(), self.z_aux_dev.data_ptr(), 1,
+            return self.sharded.prove(z_in_ptr, z_aux_ptr, on_device, self.rs[0], self.rs[1])
+        return prove_sharded(self.ctx, self.key, self.mat, z_in_ptr, z_aux_ptr, on_device,
                              self.pk_view, self.rs[0], self.rs[1], d.rank, d.world, d.dev if d.world > 1 else None,
                              split_transforms=bool(self.split))
+
+    def host_witness(self, reps):
+        """The same proof with the witness where every caller of the reference has it -- host memory
+        (zinc-vm/src/core/circuit/facade.rs:145-153 hands bellman a synthesizer, the assignment is a Vec<Fr>): the
+        PCIe copy of (n_inputs + n_aux) * 32 bytes is inside the timed call.  Pageable memory is what a Vec is;
+        page-locked memory is what a host that allocates its witness with hipHostMalloc would have."""
+        import torch
+        d = self.d
+        out = {"witness_bytes": int(self.zi.nbytes + self.za.nbytes)}
+        pageable = d.timed(lambda: self.step_with(self.zi.ctypes.data, self.za.ctypes.data, 0), reps, warmup=1)
+        out["pageable_ms_per_proof"] = 1e3 * pageable
+        try:
+            pin_i = torch.from_numpy(self.zi.view(np.int64)).pin_memory()
+            pin_a = torch.from_numpy(self.za.view(np.int64)).pin_memory()
+            pinned = d.timed(lambda: self.step_with(pin_i.data_ptr(), pin_a.data_ptr(), 0), reps, warmup=1)
+            out["pinned_ms_per_proof"] = 1e3 * pinned
+        except RuntimeError as e:
+            out["pinned_ms_per_proof"] = None
+            out["pinned_error"] = str(e)
+        resident = d.timed(self.step, reps, warmup=1)
+        out["resident_ms_per_proof"] = 1e3 * resident
+        out["workload"] = ("2^%d-row proof, witness handed over in host memory (zg16_prove, witness_on_device = 0); "
+                           "resident = the same calls with the witness already in HBM" % self.log_rows)
+        return out
 
     def free(self):
         if self.sharded:
@@ -215,7 +256,7 @@ def secondary_block(ctx, d, args, split_for):
         if d.world > 1:
             torch.distributed.barrier()
 
-    def prove_case(log_rows, dense, reps):
+    def prove_case(log_rows, dense, reps, host_witness_into=None):
         case = ProveCase(ctx, d, log_rows, dense, split_for(log_rows))
         try:
             case.step()
@@ -225,6 +266,8 @@ def secondary_block(ctx, d, args, split_for):
             stage = ctx.timings()
             ctx.profile(False, reset=False)
             n_rows = 1 << log_rows
+            if host_witness_into:
+                out[host_witness_into] = case.host_witness(reps)
             return {"workload": "synthetic zinc-shaped R1CS, 2^%d rows (%s witness), full Groth16 prove incl. G2 multiexp"
                                 % (log_rows, "dense" if dense else "80% bit"),
                     "ms_per_proof": 1e3 * sec, "constraints_per_s": n_rows / sec, "proofs_timed": reps,
@@ -285,8 +328,7 @@ def secondary_block(ctx, d, args, split_for):
                              "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": nbytes / res[0] / HBM_PEAK, "traffic": None,
                              "bytes_per_transform": nbytes}}
 
-    def msm_standalone():
-        log_n = args.secondary_log_n
+    def msm_standalone(log_n):
         n = 1 << log_n
         n_loc = n // d.world
         rng = np.random.default_rng(100 + d.rank)
@@ -310,7 +352,7 @@ def secondary_block(ctx, d, args, split_for):
                 return outs
             run()
             ctx.profile(2, reset=True)
-            sec = d.timed(run, 3, warmup=0)
+            sec = d.timed(run, 3 if log_n >= 26 else 10, warmup=0)
             stats = ctx.kernel_stats()
             ctx.profile(False, reset=False)
         finally:
@@ -353,11 +395,14 @@ def secondary_block(ctx, d, args, split_for):
                 "ms_per_proof": 1e3 * sec, "proofs_timed": 50, "verifies_against_pinned_output": bool(ok),
                 "verify_ms_host": 1e3 * verify_s, "keygen_s": keygen_s, "key_upload_and_tables_s": key_upload_s}
 
-    guarded("prove_2p%d" % args.secondary_log_rows, lambda: prove_case(args.secondary_log_rows, False, 3))
+    guarded("prove_2p%d" % args.secondary_log_rows,
+            lambda: prove_case(args.secondary_log_rows, False, 3, "prove_2p%d_host_witness" % args.secondary_log_rows))
     if d.world == 1:
         guarded("small_circuit_factorial", small_circuit)
     guarded("prove_2p%d_dense" % min(args.log_rows, 20), lambda: prove_case(min(args.log_rows, 20), True, 10))
-    guarded("msm_g1_2p%d" % args.secondary_log_n, msm_standalone)
+    # the metric's second half: G1 multiexp points per second at the two headline sizes, then the stand-alone size
+    for log_n in sorted({min(args.log_rows, 20), args.secondary_log_rows, args.secondary_log_n}):
+        guarded("msm_g1_2p%d" % log_n, lambda log_n=log_n: msm_standalone(log_n))
     guarded("fr_ntt_2p%d" % args.secondary_log_n, ntt_standalone)
     guarded("cold_start", cold_start)
     return out
@@ -483,20 +528,24 @@ def main():
                       for k, v in stats_all.items() if v[1]}
 
         pmc = {}
+        traffic_from = None
         # the newest committed counter passes of this same command (profiles/rNN_pmc_hbm_2pK.json)
         import glob
         pmc_files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
                                                   "r*_pmc_hbm_2p%d.json" % args.log_rows)))
         if pmc_files:
             pmc = json.load(open(pmc_files[-1]))["kernels"]
+            traffic_from = ("profiles/%s: rocprofv3 --pmc passes of this command on an earlier box (FETCH_SIZE and "
+                            "WRITE_SIZE in separate runs), not counters of this run" % os.path.basename(pmc_files[-1]))
 
         def traffic(pmc_name, streaming):
             """HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
             (FETCH_SIZE doubled for streaming reads as gfx950 needs; raw for gathers), or None."""
-            k = pmc.get(pmc_name)
-            if not k:
+            names = pmc_name if isinstance(pmc_name, tuple) else (pmc_name,)   # a timer that brackets several kernels
+            if not all(n in pmc for n in names):
                 return None
-            return (k["fetch_bytes_per_launch"] if streaming else k["fetch_bytes_per_launch_raw"]) + k["write_bytes_per_launch"]
+            return sum((pmc[n]["fetch_bytes_per_launch"] if streaming else pmc[n]["fetch_bytes_per_launch_raw"])
+                       + pmc[n]["write_bytes_per_launch"] for n in names)
 
         def valu_roofline(name, fq_mul_per_add, pmc_name, stats=stats):
             ms, launches, adds = stats[name]
@@ -505,16 +554,18 @@ def main():
             ach = adds * fq_mul_per_add * MAD_PER_FQ_MUL / (ms * 1e-3)
             return {"kernel": name, "bound": "valu", "achieved": ach / 1e12, "peak": VALU_MAD_PEAK / 1e12,
                     "unit": "Tmad/s", "frac": ach / VALU_MAD_PEAK, "traffic": traffic(pmc_name, False),
+                    "traffic_from": traffic_from,
                     "avg_launch_ms": ms / launches, "adds_per_launch": adds / launches,
                     "frac_of_measured_mad_rate": ach / VALU_MAD_MEASURED}
 
-        def hbm_roofline(name, pmc_name, fr_mul_per_byte=None, stats=stats):
+        def hbm_roofline(name, pmc_name, fr_mul_per_byte=None, stats=stats, streaming=True):
             ms, launches, nbytes = stats[name]
             if not launches:
                 return None
             ach = nbytes / (ms * 1e-3)
             r = {"kernel": name, "bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                 "frac": ach / HBM_PEAK, "traffic": traffic(pmc_name, True), "avg_launch_ms": ms / launches,
+                 "frac": ach / HBM_PEAK, "traffic": traffic(pmc_name, streaming), "traffic_from": traffic_from,
+                 "avg_launch_ms": ms / launches,
                  "bytes_per_launch": nbytes / launches}
             if fr_mul_per_byte:
                 # the transform is bounded by field products, not bytes: the same launches against the VALU peak
@@ -530,7 +581,8 @@ def main():
                 "k_accumulate<G1>": valu_roofline("k_accumulate<G1>", FQ_MUL_PER_G1_MADD, "k_accumulate<Fq >", st),
                 "k_accumulate<G2>": valu_roofline("k_accumulate<G2>", FQ_MUL_PER_G2_MADD, "k_accumulate<Fq2>", st),
                 "k_ntt_pass": hbm_roofline("k_ntt_pass", "k_ntt_pass", 5.25 / 64.0, st),
-                "k_spmv_short+long": hbm_roofline("k_spmv_short+long", "k_spmv_short", None, st),
+                # (the kernel a proof runs for the short rows is k_spmv_ordered; k_spmv_short only serves sharded row blocks)
+                "k_spmv_short+long": hbm_roofline("k_spmv_short+long", ("k_spmv_ordered", "k_spmv_long"), None, st, streaming=False),  # gathers: raw FETCH_SIZE
             }
 
         # live (HIP events over the timed steps, pipelines overlapped) for the dominant kernel kind, k_accumulate;
@@ -589,11 +641,18 @@ def main():
                                                            if cpu_rows == args.log_rows else None)
             out["cpu_baseline"]["sample"] = out["cpu_baseline"]["sample"].replace(
                 "(1/1 of", "(1/%d of" % (1 << (args.log_rows - args.cpu_log_rows)))
+    host_witness = None
+    if not args.no_secondary:
+        try:
+            host_witness = case.host_witness(max(3, min(args.steps, 10)))
+        except Exception as e:  # noqa: BLE001 -- must not take the headline line down
+            host_witness = {"error": "%s: %s" % (type(e).__name__, e)}
     case.free()
     del case, key, mat
     if not args.no_secondary:
         sec = secondary_block(ctx, d, args, split_for)
         if rank == 0:
+            sec["prove_2p%d_host_witness" % args.log_rows] = host_witness
             out["secondary"] = sec
     if rank == 0:
         print(json.dumps(out), flush=True)
