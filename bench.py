@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--split-transforms", choices=("auto", "on", "off", "sharded"), default="auto",
                     help="how N > 1 ranks share the transforms: off = every rank repeats them, on = the A/B/C chains on "
                          "three ranks, sharded = every transform over all ranks (2, 4 or 8), a, b, c sharded through H; "
-                         "auto: sharded from 2^21 rows on 2/4/8 ranks, chains from 2^22 rows on 3+ ranks, else off")
+                         "auto: sharded from 2^20 rows on 2/4/8 ranks, chains from 2^22 rows on 3+ ranks, else off")
     return ap.parse_args()
 
 
@@ -147,36 +147,97 @@ def rand_fr(rng, count):
     return a
 
 
+def shared_workload(ctx, d, log_rows, dense):
+    """(r1cs, params, z_in, z_aux, seconds spent on key generation) of one synthetic circuit.  With several ranks,
+    rank 0 generates circuit, key and witness ONCE and the others map its arrays: N ranks that each generated a
+    2^24-row instance would run N GPU key generations, hold N copies of 9 GB of host arrays and share the host's
+    cores among N x 16 generator threads.  The arrays travel as .npy files in a RAM-backed directory, mapped
+    read-only; the directory is removed once every rank has uploaded (ProveCase)."""
+    import shutil
+    import torch
+    from zinc_amd import workload
+    from zinc_amd.groth16 import R1CS, Parameters
+
+    def generate():
+        circ = workload.SyntheticCircuit(1 << log_rows, dense=dense)
+        r1cs = circ.r1cs()
+        t1 = time.time()
+        params = workload.generate_parameters(ctx, r1cs, TOXIC)   # zg16_generate_parameters: on the GPU
+        keygen_s = time.time() - t1
+        zi, za = circ.witness()
+        return r1cs, params, zi, za, keygen_s
+
+    if d.world == 1:
+        return generate() + (None,)
+    names = ("alpha_g1", "beta_g1", "beta_g2", "delta_g1", "delta_g2", "h", "l", "a", "b_g1", "b_g2", "gamma_g2", "ic")
+    tag = "zg16_bench_%s_%d_%d" % (os.environ.get("MASTER_PORT", "0"), log_rows, int(dense))
+    where = [None]
+    if d.rank == 0:
+        r1cs, params, zi, za, keygen_s = generate()
+        arrays = {"zi": zi, "za": za}
+        for k, (rp, col, co) in enumerate(r1cs.mats):
+            arrays.update({"rp%d" % k: rp, "col%d" % k: col, "co%d" % k: co})
+        arrays.update({n: getattr(params, n) for n in names})
+        need = sum(a.nbytes for a in arrays.values())
+        for base in (os.environ.get("ZG16_BENCH_SHARE_DIR"), "/dev/shm", "/tmp"):
+            try:
+                if base and os.path.isdir(base) and shutil.disk_usage(base).free > need + (need >> 3) + (1 << 28):
+                    path = os.path.join(base, tag)
+                    shutil.rmtree(path, ignore_errors=True)
+                    os.makedirs(path)
+                    for n, a in arrays.items():
+                        np.save(os.path.join(path, n + ".npy"), a)
+                    with open(os.path.join(path, "meta.json"), "w") as f:
+                        json.dump({"n_inputs": int(r1cs.n_inputs), "n_aux": int(r1cs.n_aux), "keygen_s": keygen_s}, f)
+                    where[0] = path
+                    break
+            except OSError:
+                shutil.rmtree(os.path.join(base, tag), ignore_errors=True)
+    torch.distributed.broadcast_object_list(where, src=0)
+    path = where[0]
+    if d.rank == 0:
+        return r1cs, params, zi, za, keygen_s, path
+    if path is None:   # nowhere to share: every rank generates its own (the seeds are fixed, so they agree)
+        return generate() + (None,)
+    ld = lambda n: np.load(os.path.join(path, n + ".npy"), mmap_mode="r")
+    meta = json.load(open(os.path.join(path, "meta.json")))
+    r1cs = R1CS(meta["n_inputs"], meta["n_aux"], [(ld("rp%d" % k), ld("col%d" % k), ld("co%d" % k)) for k in range(3)])
+    params = Parameters(*(ld(n) for n in names[:10]))
+    params.gamma_g2, params.ic = ld("gamma_g2"), ld("ic")
+    return r1cs, params, np.ascontiguousarray(ld("zi")), np.ascontiguousarray(ld("za")), meta["keygen_s"], path
+
+
 class ProveCase:
     """One synthetic circuit with its key, matrices and witness resident in HBM (this rank's key shard)."""
 
     def __init__(self, ctx, d, log_rows, dense, split):
+        import shutil
         import torch
-        from zinc_amd import workload
         from zinc_amd.fields import ints_to_mont, R_MOD
         self.ctx, self.d, self.log_rows, self.dense, self.split = ctx, d, log_rows, dense, split
         t0 = time.time()
-        self.circ = workload.SyntheticCircuit(1 << log_rows, dense=dense)
-        self.r1cs = self.circ.r1cs()
-        t1 = time.time()
-        self.params = workload.generate_parameters(ctx, self.r1cs, TOXIC)   # zg16_generate_parameters: on the GPU
-        self.keygen_s = time.time() - t1
+        self.r1cs, self.params, self.zi, self.za, self.keygen_s, shared_path = shared_workload(ctx, d, log_rows, dense)
         self.generate_s = time.time() - t0
-        t0 = time.time()
-        self.mat = self.r1cs.upload(ctx)
-        self.matrices_upload_s = time.time() - t0
-        self.sharded = None
-        if split == "sharded":
-            from zinc_amd.distributed import ShardedProver
-            self.sharded = ShardedProver(ctx, self.params, self.mat, d.rank, d.world, d.dev)
-            self.key = None
-        else:
-            self.key = self.params.upload(ctx, d.rank, d.world)
-        self.zi, self.za = self.circ.witness()
-        self.z_in_dev = torch.from_numpy(self.zi.view(np.int64)).cuda()
-        self.z_aux_dev = torch.from_numpy(self.za.view(np.int64)).cuda()
-        torch.cuda.synchronize()
-        self.upload_s = time.time() - t0
+        try:
+            t0 = time.time()
+            self.mat = self.r1cs.upload(ctx)
+            self.matrices_upload_s = time.time() - t0
+            self.sharded = None
+            if split == "sharded":
+                from zinc_amd.distributed import ShardedProver
+                self.sharded = ShardedProver(ctx, self.params, self.mat, d.rank, d.world, d.dev)
+                self.key = None
+            else:
+                self.key = self.params.upload(ctx, d.rank, d.world)
+            self.z_in_dev = torch.from_numpy(np.array(self.zi).view(np.int64)).cuda()
+            self.z_aux_dev = torch.from_numpy(np.array(self.za).view(np.int64)).cuda()
+            torch.cuda.synchronize()
+            self.upload_s = time.time() - t0
+        finally:
+            if d.world > 1:
+                torch.distributed.barrier()   # every rank has read what it needs from the shared arrays
+                if d.rank == 0 and shared_path:
+                    shutil.rmtree(shared_path, ignore_errors=True)
         # full-size r, s as Fr::rand gives
         self.rs = ints_to_mont([pow(7, 123456789, R_MOD), pow(5, 987654321, R_MOD)], R_MOD)
         self.pk_view = self.params.view()
@@ -472,14 +533,14 @@ def main():
             return "sharded" if can_shard else False
         if args.split_transforms == "on":
             return True
-        if can_shard and log_rows >= 21:
+        if can_shard and log_rows >= 20:
             return "sharded"
         return world >= 3 and log_rows >= 22
 
     t0 = time.time()
     case = ProveCase(ctx, d, args.log_rows, args.dense, split_for(args.log_rows))
     setup_s = time.time() - t0
-    circ, params, r1cs, key, mat, zi, za = case.circ, case.params, case.r1cs, case.key, case.mat, case.zi, case.za
+    params, r1cs, key, mat, zi, za = case.params, case.r1cs, case.key, case.mat, case.zi, case.za
     split = case.split
     dens = mat.density()
     step, fence = case.step, d.fence
@@ -617,7 +678,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "synthetic zinc-shaped R1CS, 2^%d rows (%s witness), full Groth16 prove incl. G2 multiexp"
                                    % (args.log_rows, "dense" if args.dense else "80% bit"),
-                       "n_inputs": circ.n_inputs, "n_aux": circ.n_aux, "nnz": [int(m[1].shape[0]) for m in r1cs.mats],
+                       "n_inputs": int(r1cs.n_inputs), "n_aux": int(r1cs.n_aux), "nnz": [int(m[1].shape[0]) for m in r1cs.mats],
                        "a_aux_density": dens[0], "b_aux_density": dens[2], "parallelism": "msm-point-range x%d%s" % (world, ", transforms sharded over all ranks" if split == "sharded" else ", A/B/C transform chains on 3 ranks" if split else "")},
             "constraints_per_s": n_rows / (ms_per_step / 1e3),
             "stage_ms_last_step": stage,

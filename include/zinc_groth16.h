@@ -270,11 +270,16 @@ unsigned    zg16_r1cs_log_domain(const zg16_r1cs* r1cs);
  *
  * Per GPU: zg16_hshard_create once per (key, circuit); then per proof, for stage = 0, 1, 2, 3:
  *     zg16_hshard_stage(hs, stage, z_in, z_aux, witness_on_device, work, got, &n)   (witness used by stage 0 only)
- *     if n > 0: exchange -- for each of the first n vectors (zg16_hshard_vector_bytes each, back to back) of `work`,
- *               chunk h (1/G of the vector) goes to GPU h, which stores the chunk it gets from GPU g at chunk g of the
- *               same vector of its `got` (an equal-split all-to-all per vector).  The call returns with `work` ready.
+ *     if n > 0: ONE exchange -- an equal-split all-to-all of the first n vectors' worth (n * zg16_hshard_vector_bytes)
+ *               of `work` into the same range of `got`: chunk h (1/G of that range) goes to GPU h, which stores the
+ *               chunk it gets from GPU g at chunk g.  The stage leaves its n vectors destination-major (chunk h holds
+ *               block h of vector 0, block h of vector 1, ...) and the next stage reads what arrived in that order, so
+ *               nothing is packed or unpacked around the collective.  The call returns with `work` ready.
  * and zg16_hshard_finish for this GPU's partial sums; zg16_prove_finish adds the partials of all GPUs.
- * work, got: device memory of the caller, 3 vectors each.  zg16_hshard_stage(.., 0, ..) restarts a proof at any time. */
+ * work, got: device memory of the caller, 3 vectors each.  zg16_hshard_stage(.., 0, ..) restarts a proof at any time.
+ * zg16_hshard_stream_ordered(hs, 1): the stages only queue their kernels on the context's stream and return; the
+ * caller queues each exchange on that same stream (zg16_ctx_set_stream with the stream its collectives are ordered
+ * on), so no host thread waits between the stages; zg16_hshard_finish still waits for the results. */
 typedef struct zg16_hshard zg16_hshard;
 zg16_status zg16_pk_upload_cyclic_h(zg16_ctx* ctx, const zg16_pk_view* view, int shard_index, int shard_count,
                                     zg16_pk** out);
@@ -284,13 +289,14 @@ void        zg16_hshard_free(zg16_hshard* hs);
 size_t      zg16_hshard_vector_bytes(const zg16_hshard* hs);
 zg16_status zg16_hshard_stage(zg16_hshard* hs, int stage, const uint64_t* z_in, const uint64_t* z_aux,
                               int witness_on_device, uint64_t* work_dev, uint64_t* got_dev, int* n_exchange);
+zg16_status zg16_hshard_stream_ordered(zg16_hshard* hs, int on);
 zg16_status zg16_hshard_finish(zg16_hshard* hs, zg16_partial* out);
 
 /* The same driven from ONE process that sees all the GPUs (what a Rust host linking this library can do without a
  * launcher): a context per listed device, a host thread per GPU during a call, peer-to-peer copies for the
  * exchanges.  zg16_multi_load shards the key and uploads the matrices to every GPU (previous ones are released);
  * sharded_transforms: 1 = the schedule above (needs 2, 4 or 8 devices), 0 = every GPU repeats the row evaluation
- * and the transforms and only the multiexps are split (any device count), -1 = choose (sharded from 2^21 rows).
+ * and the transforms and only the multiexps are split (any device count), -1 = choose (sharded from 2^20 rows).
  * zg16_multi_prove: witness and (r, s) in host memory, as zg16_prove.  A device id may be listed more than once
  * (several contexts on one GPU), which is how a one-GPU machine rehearses the schedule. */
 typedef struct zg16_multi zg16_multi;

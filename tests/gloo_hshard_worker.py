@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from oracle import cpu_binding as cb  # noqa: E402
-from zinc_amd.distributed import run_sharded_stages  # noqa: E402
+from zinc_amd.distributed import run_sharded_stages, exchange_pack, exchange_unpack  # noqa: E402
 from zinc_amd.fields import R_MOD, ints_to_mont, mont_to_ints  # noqa: E402
 
 P = R_MOD
@@ -64,30 +64,39 @@ def main():
     got = torch.zeros((3, L, 4), dtype=torch.int64)
     rd = lambda t: mont_to_ints(np.ascontiguousarray(t.numpy().view(np.uint64)), P)
 
-    def wr(t, vals):
-        t.copy_(torch.from_numpy(ints_to_mont([x % P for x in vals], P).view(np.int64)))
+    def as_t(vals):
+        return torch.from_numpy(ints_to_mont([x % P for x in vals], P).view(np.int64).copy())
+
+    flat_w, flat_g = work.reshape(-1, 4), got.reshape(-1, 4)
+
+    def send(vectors):   # the stage's vectors, destination-major, at the front of `work`
+        flat_w[:len(vectors) * L].copy_(exchange_pack([as_t(v) for v in vectors], world))
+        return len(vectors)
+
+    def received(n):     # the n vectors the last exchange delivered, natural order
+        return [rd(v.contiguous()) for v in exchange_unpack(flat_g[:n * L], n, world)]
 
     state = {}
 
     def stage(k):
         if k == 0:     # this rank's blocks of rows, then the cross step of the inverse transform
             rows = [(j // blk) * L + rank * blk + (j % blk) for j in range(L)]
-            for v, vec in enumerate((a, b, c)):
-                wr(work[v], cross([vec[r] for r in rows], True))
-            return 3
+            return send([cross([vec[r] for r in rows], True) for vec in (a, b, c)])
         if k == 1:     # c' = ifft(c) / Z; a, b: ifft, times g^i, forward local transform
-            cc = local_ntt(rd(got[2]), True)
+            ga, gb, gc = received(3)
+            cc = local_ntt(gc, True)
             state["c"] = [x * inv(L) * z_inv % P for x in cc]
-            for v in range(2):
-                co = local_ntt(rd(got[v]), True)
+            out = []
+            for vec in (ga, gb):
+                co = local_ntt(vec, True)
                 co = [x * inv(L) * pow(g, rank + G * j, P) % P for j, x in enumerate(co)]
-                wr(work[v], local_ntt(co, False))
-            return 2
+                out.append(local_ntt(co, False))
+            return send(out)
         if k == 2:     # coset evaluations, their product, cross step of the last inverse transform
-            A, B = cross(rd(got[0]), False), cross(rd(got[1]), False)
-            wr(work[0], cross([x * y % P for x, y in zip(A, B)], True))
-            return 1
-        h = local_ntt(rd(got[0]), True)
+            ga, gb = received(2)
+            A, B = cross(ga, False), cross(gb, False)
+            return send([cross([x * y % P for x, y in zip(A, B)], True)])
+        h = local_ntt(received(1)[0], True)
         state["h"] = [(x * inv(L) * pow(inv(g), rank + G * j, P) * z_inv - state["c"][j]) % P for j, x in enumerate(h)]
         return 0
 

@@ -801,7 +801,7 @@ def _run_ranks(script, world, port, *args):
     outs = []
     for p in procs:
         try:
-            outs.append(p.communicate(timeout=100)[0].decode())
+            outs.append(p.communicate(timeout=240)[0].decode())
         except subprocess.TimeoutExpired:
             for q in procs:
                 q.kill()
@@ -834,7 +834,7 @@ def test_sharded_prove_with_split_transforms(world):
     outs = []
     for p in procs:
         try:
-            outs.append(p.communicate(timeout=100)[0].decode())
+            outs.append(p.communicate(timeout=240)[0].decode())
         except subprocess.TimeoutExpired:
             for q in procs:
                 q.kill()
@@ -878,17 +878,19 @@ def test_spmv_coefficient_codes(gpu_ctx):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 4])
-def test_sharded_transforms_over_ranks_prove(world):
+@pytest.mark.parametrize("world,log_rows", [(2, 12), (4, 12), (2, 16), (4, 20)])
+def test_sharded_transforms_over_ranks_prove(world, log_rows):
     """`world` processes on one GPU (gloo stands in for RCCL): a, b, c stay sharded through the whole H computation
-    (zg16_hshard_*), h query cyclic -- bit-identical to zg16_prove."""
-    outs = _run_ranks("gpu_hshard_worker.py", world, 29560 + world, 12)
+    (zg16_hshard_*: one destination-major exchange per stage), h query cyclic -- bit-identical to zg16_prove, up to
+    the headline size."""
+    outs = _run_ranks("gpu_hshard_worker.py", world, 29600 + world + log_rows, log_rows)
     assert "bit-identical" in outs[0], outs[0]
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("devices,sharded,log_rows", [([0, 0], True, 12), ([0, 0, 0, 0], True, 12), ([0, 0], True, 16),
-                                                       ([0, 0, 0, 0], True, 16), ([0] * 8, True, 13), ([0, 0, 0], False, 12)])
+                                                       ([0, 0, 0, 0], True, 16), ([0] * 8, True, 13), ([0, 0, 0], False, 12),
+                                                       ([0] * 8, True, 20), ([0, 0], None, 20)])
 def test_multi_gpu_prover_in_one_process(gpu_ctx, devices, sharded, log_rows):
     """zg16_multi_*: one process, a context per listed device (all on GPU 0 here), peer copies for the exchanges.
     Sharded transforms at 2, 4 and 8 shards and the replicated schedule at 3: the proof equals zg16_prove's."""
@@ -904,7 +906,8 @@ def test_multi_gpu_prover_in_one_process(gpu_ctx, devices, sharded, log_rows):
     key.free()
     mat.free()
     mp = MultiProver(devices)
-    assert mp.load(params, r1cs, sharded_transforms=sharded) == sharded
+    # sharded None: the library chooses (sharded from 2^20 rows when the device count allows it)
+    assert mp.load(params, r1cs, sharded_transforms=sharded) == (True if sharded is None else sharded)
     for _ in range(2):
         got = mp.prove(zi, za, rs[0], rs[1])
         assert got.as_tuple() == want.as_tuple()

@@ -1,8 +1,14 @@
-"""What ONE rank of an N-rank proof does, timed alone on one GPU: zg16_prove_partial on shard 0 of N of the key
-(every rank repeats the row evaluation and the transforms below 2^21 rows; the multiexps cover 1/N of the points).
-The gather of the 640-byte partial sums and the host assembly are not in it.
+"""What ONE rank of an N-rank proof does, timed alone on one GPU.
 
-    python tools/rank_share.py [--log-rows 20]
+Replicated schedule: zg16_prove_partial on shard 0 of N of the key (every rank repeats the row evaluation and the
+transforms; the multiexps cover 1/N of the points).
+Sharded schedule (--schedule sharded): shard 0's four zg16_hshard_stage calls, stream-ordered as over RCCL, with each
+exchange replaced by a device copy of the same bytes from `work` to `got` on that stream (what arrives is then not
+the other ranks' data, but it is dense field elements like theirs: the kernels' work is the same).  The time of the
+real all-to-alls is NOT in it: at 2^20 rows on 8 GPUs they move 3.5 + 2.3 + 1.2 MiB per GPU and direction.
+The gather of the 640-byte partial sums and the host assembly are not in either.
+
+    python tools/rank_share.py [--log-rows 20] [--schedule replicated|sharded]
 """
 import argparse
 import ctypes as C
@@ -20,6 +26,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--log-rows", type=int, default=20)
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--schedule", choices=("replicated", "sharded"), default="replicated")
     args = ap.parse_args()
     import torch
     torch.cuda.set_device(0)
@@ -34,6 +41,8 @@ def main():
     zi, za = circ.witness()
     zi_d = torch.from_numpy(zi.view(np.int64)).cuda()
     za_d = torch.from_numpy(za.view(np.int64)).cuda()
+    if args.schedule == "sharded":
+        return sharded(args, ctx, params, mat, zi_d, za_d)
     for n in (1, 2, 4, 8):
         key = params.upload(ctx, 0, n)
         part = zlib.Partial()
@@ -51,6 +60,49 @@ def main():
         ms = 1e3 * (time.perf_counter() - t0) / args.reps
         print("ranks %d: shard 0 alone %.3f ms per proof; stage ms %s" % (n, ms, {k: round(v, 3) for k, v in ctx.timings().items()}), flush=True)
         key.free()
+
+
+def sharded(args, ctx, params, mat, zi_d, za_d):
+    import torch
+    from zinc_amd import lib as zlib
+    from zinc_amd.groth16 import _check
+    L = ctx._lib
+    stream = torch.cuda.Stream()
+    for n in (2, 4, 8):
+        log_g = n.bit_length() - 1
+        view = params.view()
+        key, hs = C.c_void_p(), C.c_void_p()
+        _check(ctx.handle, L.zg16_pk_upload_cyclic_h(ctx.handle, C.byref(view), 0, n, C.byref(key)))
+        _check(ctx.handle, L.zg16_hshard_create(ctx.handle, key, mat.handle, log_g, 0, C.byref(hs)))
+        rows = L.zg16_hshard_vector_bytes(hs) // 32
+        work = torch.zeros((3 * rows, 4), dtype=torch.int64, device="cuda")
+        got = torch.zeros((3 * rows, 4), dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        ctx.set_stream(stream.cuda_stream)
+        _check(ctx.handle, L.zg16_hshard_stream_ordered(hs, 1))
+        part = zlib.Partial()
+
+        def step():
+            with torch.cuda.stream(stream):
+                for k in range(4):
+                    nx = C.c_int()
+                    _check(ctx.handle, L.zg16_hshard_stage(hs, k, C.c_void_p(zi_d.data_ptr()), C.c_void_p(za_d.data_ptr()), 1,
+                                                           C.c_void_p(work.data_ptr()), C.c_void_p(got.data_ptr()), C.byref(nx)))
+                    if nx.value:
+                        got[:nx.value * rows].copy_(work[:nx.value * rows])
+                _check(ctx.handle, L.zg16_hshard_finish(hs, C.byref(part)))
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.reps):
+            step()
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / args.reps
+        print("ranks %d, sharded schedule: shard 0 alone %.3f ms per proof (exchanges as device copies)" % (n, ms), flush=True)
+        ctx.set_stream(None)
+        L.zg16_hshard_free(hs)
+        L.zg16_pk_free(key)
 
 
 if __name__ == "__main__":

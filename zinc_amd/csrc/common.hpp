@@ -295,14 +295,22 @@ void ntt_free_domains(zg16_ctx* ctx);
 void ntt_free_cross_tables(zg16_ctx* ctx);
 void ntt_free_hshard_tables(zg16_ctx* ctx);
 struct HShardTables;
+// A vector held as chunks of 2^log_blk elements, consecutive chunks `stride` elements apart (stride 0: contiguous).
+struct ChunkLayout {
+  uint32_t log_blk;
+  size_t stride;
+};
 zg16_status hshard_tables(zg16_ctx* ctx, unsigned log_m, unsigned log_g, unsigned shard, const HShardTables** out);
 zg16_status hshard_local_ntt(zg16_ctx* ctx, unsigned log_l, const HShardTables* t, const Fr* src, Fr* dst, bool inverse,
-                             int which, const Fr* subvec);
+                             int which, const Fr* subvec, const ChunkLayout* src_chunks = nullptr,
+                             const ChunkLayout* dst_chunks = nullptr);
 zg16_status mul_vec_device(zg16_ctx* ctx, Fr* a, const Fr* b, size_t n);
 // out[i] = c * base^i, i < count (device memory, the context's stream)
 zg16_status pow_table_device(zg16_ctx* ctx, Fr* out, size_t count, const Fr& base, const Fr& c);
 // The cross-GPU step of a 2^log_n-point transform sharded over 2^log_g GPUs (see ntt.hip), in place on
 // this shard's 2^(log_n - log_g) elements.
 zg16_status ntt_cross_device(zg16_ctx* ctx, Fr* data, unsigned log_n, unsigned log_g, unsigned shard, bool inverse);
+zg16_status ntt_cross_chunked(zg16_ctx* ctx, const Fr* in, size_t in_stride, Fr* out, size_t out_stride, unsigned log_n,
+                              unsigned log_g, unsigned shard, bool inverse, const Fr* mulvec);
 
 }  // namespace zg

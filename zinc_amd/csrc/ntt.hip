@@ -31,6 +31,10 @@ struct PassParams {
   uint32_t tw_scale;  // inter-pass twiddle exponent scale (k_pass_twiddles), 0: none
   uint32_t load_j_fast;
   uint32_t nq;  // non-zero: logical tile L splits as q = L % nq, rem = L / nq (q fastest) instead of by bdiv
+  // Chunked operands (a sharded proof's exchange buffers): the vector's natural index i lives at
+  // (i >> rlog) * rstride + (i & (2^rlog - 1)) -- chunk i >> rlog of 2^rlog elements starts rstride elements after
+  // the previous one.  rstride = 0: the vector is contiguous.  Factor tables, mulvec and subvec stay natural.
+  uint32_t in_rlog, in_rstride, out_rlog, out_rstride;
 };
 
 // N = R1*R2*R3: the passes of one transform and their launch sizes
@@ -164,7 +168,9 @@ __global__ __launch_bounds__(256, 4) void k_ntt_pass(const Fr* __restrict__ in, 
       t = idx & (T - 1);
       j = idx >> logT;
     }
-    const Fr x = in[in_base + j * p.in_jstride + t * p.in_tstride];
+    uint32_t src = in_base + j * p.in_jstride + t * p.in_tstride;
+    if (p.in_rstride) src = (src >> p.in_rlog) * p.in_rstride + (src & ((1u << p.in_rlog) - 1));
+    const Fr x = in[src];
     lds_put(s, (t << logR) + (__brev(j) >> (32 - logR)), unpack29<Fr29Params>(x));
   }
   __syncthreads();
@@ -231,7 +237,7 @@ __global__ __launch_bounds__(256, 4) void k_ntt_pass(const Fr* __restrict__ in, 
       f = Fr29::one();
     Fr r = pack29<Fr29Params, FrParams>(mul(v, f));
     if (ex.subvec) r = sub(r, ex.subvec[o]);
-    out[o] = r;
+    out[p.out_rstride ? (o >> p.out_rlog) * p.out_rstride + (o & ((1u << p.out_rlog) - 1)) : o] = r;
   }
 }
 
@@ -566,7 +572,8 @@ void ntt_free_domains(zg16_ctx* ctx) {
 // alias src.  The factor rides on the last pass's store, so `ifft` followed by a coset scaling (or
 // `icoset_fft`'s trailing g^-i / m) costs no extra product and no extra pass.
 static zg16_status ntt_raw(zg16_ctx* ctx, NttDomain* d, const Fr* src, Fr* dst, bool inverse,
-                           const Fr29* post_scale = nullptr, const PassExtras* last = nullptr) {
+                           const Fr29* post_scale = nullptr, const PassExtras* last = nullptr,
+                           const ChunkLayout* src_chunks = nullptr, const ChunkLayout* dst_chunks = nullptr) {
   const unsigned n = d->log_n;
   if (n == 0) {
     if (dst != src) ZG_HIP(ctx, hipMemcpyAsync(dst, src, sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
@@ -579,9 +586,20 @@ static zg16_status ntt_raw(zg16_ctx* ctx, NttDomain* d, const Fr* src, Fr* dst, 
   if (pl.r1) ZG_TRY(scratch_get(ctx, 0, sizeof(Fr) << n, (void**)&tmp));
   hipStream_t st = ctx->stream;
   const double bytes = 64.0 * (double)((size_t)1 << n);
+  // a chunked source is read by the first pass, a chunked destination written by the last
+  PassParams first = pl.r1 ? pl.a : pl.c, last_pass = pl.c;
+  if (src_chunks && src_chunks->stride) {
+    first.in_rlog = src_chunks->log_blk;
+    first.in_rstride = (uint32_t)src_chunks->stride;
+    if (!pl.r1) last_pass = first;
+  }
+  if (dst_chunks && dst_chunks->stride) {
+    last_pass.out_rlog = dst_chunks->log_blk;
+    last_pass.out_rstride = (uint32_t)dst_chunks->stride;
+  }
   if (pl.r1) {
     KernelTimer kt(ctx, K_NTT_PASS, bytes);
-    k_ntt_pass<<<pl.grid_a, 256, 0, st>>>(src, tmp, pl.a, d->w_small[dir], PassExtras{d->tw_a[dir], nullptr, nullptr, 0});
+    k_ntt_pass<<<pl.grid_a, 256, 0, st>>>(src, tmp, first, d->w_small[dir], PassExtras{d->tw_a[dir], nullptr, nullptr, 0});
   }
   if (pl.r2) {
     KernelTimer kt(ctx, K_NTT_PASS, bytes);
@@ -589,7 +607,7 @@ static zg16_status ntt_raw(zg16_ctx* ctx, NttDomain* d, const Fr* src, Fr* dst, 
   }
   {
     KernelTimer kt(ctx, K_NTT_PASS, bytes);
-    k_ntt_pass<<<pl.grid_c, 256, 0, st>>>(pl.r1 ? tmp : src, dst, pl.c, d->w_small[dir],
+    k_ntt_pass<<<pl.grid_c, 256, 0, st>>>(pl.r1 ? tmp : src, dst, last_pass, d->w_small[dir],
                                           last ? *last : PassExtras{post_scale, nullptr, nullptr, 0});
   }
   ZG_HIP(ctx, hipGetLastError());
@@ -757,7 +775,7 @@ void ntt_free_hshard_tables(zg16_ctx* ctx) {
 // One local L-point transform of the sharded pipeline, unnormalised, with what rides on its last store:
 // which = 0: nothing; 1: times gm[j]; 2: times the constant kz; 3: times hz[j], minus subvec[j].
 zg16_status hshard_local_ntt(zg16_ctx* ctx, unsigned log_l, const HShardTables* t, const Fr* src, Fr* dst, bool inverse,
-                             int which, const Fr* subvec) {
+                             int which, const Fr* subvec, const ChunkLayout* src_chunks, const ChunkLayout* dst_chunks) {
   NttDomain* d;
   ZG_TRY(get_domain(ctx, log_l, &d));
   if (log_l == 0) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "a sharded transform needs at least two elements per GPU");
@@ -765,7 +783,7 @@ zg16_status hshard_local_ntt(zg16_ctx* ctx, unsigned log_l, const HShardTables* 
   if (which == 1) ex.factor = t->gm;
   if (which == 2) { ex.factor = t->kz; ex.factor_const = 1; }
   if (which == 3) { ex.factor = t->hz; ex.subvec = subvec; }
-  return ntt_raw(ctx, d, src, dst, inverse, nullptr, &ex);
+  return ntt_raw(ctx, d, src, dst, inverse, nullptr, &ex, src_chunks, dst_chunks);
 }
 
 __global__ __launch_bounds__(256) void k_mul_vec(Fr* a, const Fr* __restrict__ b, uint32_t n) {
@@ -792,16 +810,19 @@ struct CrossRoots {
   Fr w[4];  // w_G^j (or its inverse), j < G/2
 };
 
+// in / out: block g of the vector at g * in_stride / g * out_stride elements (blk when contiguous; in may be out).
+// mulvec (forward only): the result is multiplied element-wise by the natural-order vector mulvec (block g at g blk).
 template <int LG>
-__global__ __launch_bounds__(256) void k_ntt_cross(Fr* data, uint32_t blk, const Fr* __restrict__ tw, CrossRoots roots,
-                                                   Fr scale0, int inverse) {
+__global__ __launch_bounds__(256) void k_ntt_cross(const Fr* in, size_t in_stride, Fr* out, size_t out_stride, uint32_t blk,
+                                                   const Fr* __restrict__ tw, CrossRoots roots, Fr scale0, int inverse,
+                                                   const Fr* __restrict__ mulvec) {
   constexpr int G = 1 << LG;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= blk) return;
   Fr y[G];
 #pragma unroll
   for (int g = 0; g < G; g++) {
-    Fr x = data[(size_t)g * blk + i];
+    Fr x = in[(size_t)g * in_stride + i];
     if (!inverse && g) x = mul(x, tw[(size_t)(g - 1) * blk + i]);
     y[__brev((unsigned)g) >> (32 - LG)] = x;
   }
@@ -820,7 +841,8 @@ __global__ __launch_bounds__(256) void k_ntt_cross(Fr* data, uint32_t blk, const
   for (int g = 0; g < G; g++) {
     Fr x = y[g];
     if (inverse) x = mul(x, g ? tw[(size_t)(g - 1) * blk + i] : scale0);
-    data[(size_t)g * blk + i] = x;
+    if (mulvec) x = mul(x, mulvec[(size_t)g * blk + i]);
+    out[(size_t)g * out_stride + i] = x;
   }
 }
 
@@ -832,8 +854,20 @@ void ntt_free_cross_tables(zg16_ctx* ctx) {
 }
 
 zg16_status ntt_cross_device(zg16_ctx* ctx, Fr* data, unsigned log_n, unsigned log_g, unsigned shard, bool inverse) {
-  if (log_g == 0) return ZG16_OK;
+  return ntt_cross_chunked(ctx, data, 0, data, 0, log_n, log_g, shard, inverse, nullptr);
+}
+
+// The same with the blocks of the input and of the output `in_stride` / `out_stride` elements apart (0: contiguous)
+// and, for a forward step, an element-wise product with `mulvec` riding on the store.
+zg16_status ntt_cross_chunked(zg16_ctx* ctx, const Fr* in, size_t in_stride, Fr* out, size_t out_stride, unsigned log_n,
+                              unsigned log_g, unsigned shard, bool inverse, const Fr* mulvec) {
   const uint32_t G = 1u << log_g, blk = 1u << (log_n - 2 * log_g);
+  if (log_g == 0) {
+    if (in != out) ZG_HIP(ctx, hipMemcpyAsync(out, in, (sizeof(Fr) << log_n), hipMemcpyDeviceToDevice, ctx->stream));
+    return ZG16_OK;
+  }
+  if (!in_stride) in_stride = blk;
+  if (!out_stride) out_stride = blk;
   Fr omega = host_root_of_unity();
   for (unsigned i = log_n; i < 28; i++) omega = sqr(omega);
   if (inverse) omega = inv(omega);
@@ -864,9 +898,9 @@ zg16_status ntt_cross_device(zg16_ctx* ctx, Fr* data, unsigned log_n, unsigned l
   const Fr scale0 = inverse ? g_inv : Fr::one();
   const unsigned grid = (blk + 255) / 256;
   switch (log_g) {
-    case 1: k_ntt_cross<1><<<grid, 256, 0, st>>>(data, blk, tw, roots, scale0, inverse); break;
-    case 2: k_ntt_cross<2><<<grid, 256, 0, st>>>(data, blk, tw, roots, scale0, inverse); break;
-    default: k_ntt_cross<3><<<grid, 256, 0, st>>>(data, blk, tw, roots, scale0, inverse); break;
+    case 1: k_ntt_cross<1><<<grid, 256, 0, st>>>(in, in_stride, out, out_stride, blk, tw, roots, scale0, inverse, mulvec); break;
+    case 2: k_ntt_cross<2><<<grid, 256, 0, st>>>(in, in_stride, out, out_stride, blk, tw, roots, scale0, inverse, mulvec); break;
+    default: k_ntt_cross<3><<<grid, 256, 0, st>>>(in, in_stride, out, out_stride, blk, tw, roots, scale0, inverse, mulvec); break;
   }
   ZG_HIP(ctx, hipGetLastError());
   return ZG16_OK;

@@ -17,6 +17,14 @@
 // (icoset_fft is linear, so icoset_fft((A B - C) / Z) = icoset_fft(A B) / Z - ifft(c) / Z: c needs no coset
 // evaluation.)  The multiexps over the witness (l, a, b_g1, b_g2) start in stage 0 on their own streams.
 //
+// One exchange per stage.  The n vectors a stage hands over leave it DESTINATION-MAJOR: chunk h of `work` (n blk
+// elements: block h of vector 0, block h of vector 1, ...) is everything GPU h gets from this one, so the stage's
+// whole exchange is a single equal-split all-to-all of the first n L elements, and GPU h finds the block it got from
+// GPU g for vector v at (g n + v) blk of `got`.  The kernels on either side write and read those layouts directly
+// (chunk strides in the cross-GPU step, an index remap in the first / last pass of a local transform): nothing is
+// packed or unpacked in between.  At 2^20 rows on 8 GPUs a vector is 4 MiB per GPU and an exchange is bound by the
+// collective's launch latency, not by the links, so three exchanges per proof instead of six is what counts.
+//
 // The stages are exported one by one so that any transport can carry the exchanges: zg16_multi_* below drives
 // several GPUs from one process with peer copies; zinc_amd/distributed.py drives one process per GPU with RCCL.
 #include <string.h>
@@ -40,6 +48,8 @@ struct zg16_hshard {
   const HShardTables* tables = nullptr;
   Fr* c_coef = nullptr;  // L: ifft(c) / Z at this GPU's indices
   Fr* h = nullptr;       // L: the H coefficients at this GPU's indices
+  Fr* tmp = nullptr;     // 3 L: vectors between the steps of a stage, natural order
+  bool stream_ordered = false;  // stages only queue their work; the caller orders the exchanges on the context's stream
   MsmPending pend_g2, pend_z, pend_h;
   hipEvent_t ev_z = nullptr, ev_g2 = nullptr, ev_early = nullptr;
   int next_stage = 0;
@@ -68,6 +78,7 @@ zg16_status zg16_hshard_create(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1cs
   const size_t L = (size_t)1 << hs->log_l;
   ZG_HIP(ctx, hipMalloc((void**)&hs->c_coef, L * sizeof(Fr)));
   ZG_HIP(ctx, hipMalloc((void**)&hs->h, L * sizeof(Fr)));
+  ZG_HIP(ctx, hipMalloc((void**)&hs->tmp, 3 * L * sizeof(Fr)));
   ZG_HIP(ctx, hipEventCreateWithFlags(&hs->ev_z, hipEventDisableTiming));
   ZG_HIP(ctx, hipEventCreateWithFlags(&hs->ev_g2, hipEventDisableTiming));
   ZG_HIP(ctx, hipEventCreateWithFlags(&hs->ev_early, hipEventDisableTiming));
@@ -83,6 +94,7 @@ void zg16_hshard_free(zg16_hshard* hs) {
   }
   (void)hipFree(hs->c_coef);
   (void)hipFree(hs->h);
+  (void)hipFree(hs->tmp);
   if (hs->ev_z) (void)hipEventDestroy(hs->ev_z);
   if (hs->ev_g2) (void)hipEventDestroy(hs->ev_g2);
   if (hs->ev_early) (void)hipEventDestroy(hs->ev_early);
@@ -90,6 +102,12 @@ void zg16_hshard_free(zg16_hshard* hs) {
 }
 
 size_t zg16_hshard_vector_bytes(const zg16_hshard* hs) { return hs ? sizeof(Fr) << hs->log_l : 0; }
+
+zg16_status zg16_hshard_stream_ordered(zg16_hshard* hs, int on) {
+  if (!hs) return ZG16_ERR_INVALID_ARGUMENT;
+  hs->stream_ordered = on != 0;
+  return ZG16_OK;
+}
 
 zg16_status zg16_hshard_stage(zg16_hshard* hs, int stage, const uint64_t* z_in, const uint64_t* z_aux, int witness_on_device,
                               uint64_t* work_dev, uint64_t* got_dev, int* n_exchange) {
@@ -104,17 +122,20 @@ zg16_status zg16_hshard_stage(zg16_hshard* hs, int stage, const uint64_t* z_in, 
   const size_t L = (size_t)1 << hs->log_l, m = (size_t)1 << hs->log_m;
   Fr* work = (Fr*)work_dev;
   Fr* got = (Fr*)got_dev;
+  Fr* tmp = hs->tmp;
   hipStream_t st = ctx->stream;
   int n_ex = 0;
+  const uint32_t log_blk = hs->log_l - hs->log_g;
+  const size_t blk = (size_t)1 << log_blk;
   if (stage == 0) {
     hs->t_begin = std::chrono::steady_clock::now();
     Fr* z;
     ZG_TRY(stage_witness(ctx, r, z_in, z_aux, witness_on_device, &z));
     ZG_HIP(ctx, hipEventRecord(hs->ev_z, st));
     // rows first: the transforms are the critical path; the witness multiexps fill the GPU beside them
-    const uint32_t log_blk = hs->log_l - hs->log_g;
-    ZG_TRY(spmv_blocks_device(ctx, r, z, work, work + L, work + 2 * L, log_blk, (uint32_t)L, hs->shard << log_blk, (uint32_t)L));
-    for (int v = 0; v < 3; v++) ZG_TRY(ntt_cross_device(ctx, work + v * L, hs->log_m, hs->log_g, hs->shard, true));
+    ZG_TRY(spmv_blocks_device(ctx, r, z, tmp, tmp + L, tmp + 2 * L, log_blk, (uint32_t)L, hs->shard << log_blk, (uint32_t)L));
+    for (int v = 0; v < 3; v++)
+      ZG_TRY(ntt_cross_chunked(ctx, tmp + v * L, 0, work + v * blk, 3 * blk, hs->log_m, hs->log_g, hs->shard, true, nullptr));
     char* pinned = (char*)ctx->pinned;
     const uint32_t tc = pk->table_c;
     // the witness launch sorts for b_g2 as well when the digit widths agree (see prove_partial_impl)
@@ -142,17 +163,19 @@ zg16_status zg16_hshard_stage(zg16_hshard* hs, int stage, const uint64_t* z_in, 
     }
     n_ex = 3;
   } else if (stage == 1) {
-    ZG_TRY(hshard_local_ntt(ctx, hs->log_l, hs->tables, got + 2 * L, hs->c_coef, true, 2, nullptr));
+    // what arrived: block g of vector v at (3 g + v) blk; what leaves: block h of vector v at (2 h + v) blk
+    const ChunkLayout in3 = {log_blk, 3 * blk}, out2 = {log_blk, 2 * blk};
+    ZG_TRY(hshard_local_ntt(ctx, hs->log_l, hs->tables, got + 2 * blk, hs->c_coef, true, 2, nullptr, &in3, nullptr));
     for (int v = 0; v < 2; v++) {
-      ZG_TRY(hshard_local_ntt(ctx, hs->log_l, hs->tables, got + v * L, got + v * L, true, 1, nullptr));
-      ZG_TRY(hshard_local_ntt(ctx, hs->log_l, hs->tables, got + v * L, work + v * L, false, 0, nullptr));
+      ZG_TRY(hshard_local_ntt(ctx, hs->log_l, hs->tables, got + v * blk, tmp + v * L, true, 1, nullptr, &in3, nullptr));
+      ZG_TRY(hshard_local_ntt(ctx, hs->log_l, hs->tables, tmp + v * L, work + v * blk, false, 0, nullptr, nullptr, &out2));
     }
     n_ex = 2;
   } else if (stage == 2) {
-    for (int v = 0; v < 2; v++) ZG_TRY(ntt_cross_device(ctx, got + v * L, hs->log_m, hs->log_g, hs->shard, false));
-    ZG_TRY(mul_vec_device(ctx, got, got + L, L));
-    ZG_TRY(ntt_cross_device(ctx, got, hs->log_m, hs->log_g, hs->shard, true));
-    ZG_HIP(ctx, hipMemcpyAsync(work, got, L * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+    // the coset evaluations of a, then those of b times a's as they are stored, then the inverse cross step
+    ZG_TRY(ntt_cross_chunked(ctx, got, 2 * blk, tmp, 0, hs->log_m, hs->log_g, hs->shard, false, nullptr));
+    ZG_TRY(ntt_cross_chunked(ctx, got + blk, 2 * blk, tmp + L, 0, hs->log_m, hs->log_g, hs->shard, false, tmp));
+    ZG_TRY(ntt_cross_chunked(ctx, tmp + L, 0, work, 0, hs->log_m, hs->log_g, hs->shard, true, nullptr));
     n_ex = 1;
   } else {
     ZG_TRY(hshard_local_ntt(ctx, hs->log_l, hs->tables, got, hs->h, true, 3, hs->c_coef));
@@ -164,8 +187,9 @@ zg16_status zg16_hshard_stage(zg16_hshard* hs, int stage, const uint64_t* z_in, 
     const MsmStreams ms = {st, nullptr, nullptr, nullptr};
     ZG_TRY(msm_launch<Fq>(ctx, ms, 1, ctx->pinned, &job_h, 1, 1, &hs->pend_h));
   }
-  // the caller moves `work` next (or reads the results): everything this stage queued on the main stream is done first
-  ZG_HIP(ctx, hipStreamSynchronize(st));
+  // the caller moves `work` next (or reads the results): everything this stage queued on the main stream is done
+  // first -- unless the caller queues the exchange on that same stream, where the order is the stream's
+  if (!hs->stream_ordered) ZG_HIP(ctx, hipStreamSynchronize(st));
   hs->next_stage = stage + 1;
   if (n_exchange) *n_exchange = n_ex;
   return ZG16_OK;
@@ -315,8 +339,8 @@ zg16_status zg16_multi_load(zg16_multi* mg, const zg16_pk_view* key, const zg16_
     return ZG16_ERR_INVALID_ARGUMENT;
   }
   // by default the transforms are sharded where they are a visible share of the proof (replicating them costs every
-  // GPU about 1 ms at 2^20 rows and 14 ms at 2^24, against three all-to-all rounds)
-  mg->sharded = can_shard && (sharded_transforms > 0 || (sharded_transforms < 0 && log_m >= 21));
+  // GPU about 1 ms at 2^20 rows and 14 ms at 2^24, against three all-to-all rounds of one collective each)
+  mg->sharded = can_shard && (sharded_transforms > 0 || (sharded_transforms < 0 && log_m >= 20));
   mg->log_g = log_g;
   mg->n_in = circuit->n_inputs;
   mg->n_aux = circuit->n_aux;
@@ -384,12 +408,12 @@ zg16_status zg16_multi_prove(zg16_multi* mg, const uint64_t* z_in, const uint64_
         if (stage == 3) break;
         barrier.wait();  // every GPU's `work` is complete and every GPU is done reading its `got`
         if (st[g] == ZG16_OK && hipSetDevice(mg->device[g]) == hipSuccess) {
-          // chunk h of every vector goes to GPU h, which stores what it gets from GPU g at chunk g
+          // chunk h (block h of each of the stage's vectors) goes to GPU h, which stores what it gets from GPU g at chunk g
           hipError_t e = hipSuccess;
-          for (int v = 0; v < n_ex && e == hipSuccess; v++)
-            for (int h = 0; h < n && e == hipSuccess; h++)
-              e = hipMemcpyPeerAsync(mg->got[h] + v * L + (size_t)g * blk, mg->device[h], mg->work[g] + v * L + (size_t)h * blk,
-                                     mg->device[g], blk * sizeof(Fr), ctx->stream);
+          const size_t chunk = (size_t)n_ex * blk;
+          for (int h = 0; h < n && e == hipSuccess; h++)
+            e = hipMemcpyPeerAsync(mg->got[h] + (size_t)g * chunk, mg->device[h], mg->work[g] + (size_t)h * chunk,
+                                   mg->device[g], chunk * sizeof(Fr), ctx->stream);
           if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
           if (e != hipSuccess) st[g] = fail(ctx, ZG16_ERR_DEVICE, "peer copy failed: %s", hipGetErrorString(e));
         }

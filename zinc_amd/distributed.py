@@ -125,26 +125,53 @@ def prove_sharded(ctx, key, mat, z_in_ptr, z_aux_ptr, on_device, pk_view, r_mont
 
 
 # ---- transforms sharded through the whole H computation ----------------------------------------------
-def run_sharded_stages(stage, work, got, world, device=None, after_exchange=None):
+def exchange_pack(vectors, world):
+    """n natural-order (L, 4) vectors -> the (n L, 4) destination-major buffer a stage hands to its one exchange:
+    chunk h holds block h of vector 0, block h of vector 1, ...  (What zg16_hshard_stage writes directly; used by the
+    CPU stand-ins of the gloo rehearsal.)"""
+    import torch
+    n, length = len(vectors), vectors[0].shape[0]
+    blk = length // world
+    return torch.stack([v.reshape(world, blk, 4) for v in vectors], dim=1).reshape(n * length, 4)
+
+
+def exchange_unpack(flat, n, world):
+    """The (n L, 4) buffer an exchange delivered (the block from rank g for vector v at (g n + v) blk) -> n
+    natural-order (L, 4) vectors."""
+    blk = flat.shape[0] // (n * world)
+    t = flat.reshape(world, n, blk, 4)
+    return [t[:, v].reshape(world * blk, 4) for v in range(n)]
+
+
+def run_sharded_stages(stage, work, got, world, device=None, after_exchange=None, stream_ordered=False):
     """The stage / exchange loop of a proof whose transforms are sharded (zg16_hshard_stage's contract): call
-    stage(k) for k = 0..3; it leaves n vectors to exchange in work[0..n); each goes through one equal-split
-    all-to-all into got[v].  work, got: (3, L, 4) int64 tensors; stage is the library call on the GPU and a CPU
-    stand-in in the gloo rehearsal (tests/gloo_hshard_worker.py)."""
+    stage(k) for k = 0..3; it leaves n vectors, destination-major, in the first n L elements of `work`; ONE
+    equal-split all-to-all moves them into the same range of `got`.  work, got: (3, L, 4) int64 tensors; stage is the
+    library call on the GPU and a CPU stand-in in the gloo rehearsal (tests/gloo_hshard_worker.py).
+    stream_ordered: the stages and the collectives are queued on one stream (RCCL), nothing waits on the host."""
+    length = work.shape[1]
+    flat_w, flat_g = work.reshape(-1, 4), got.reshape(-1, 4)
     for k in range(4):
         n = stage(k)
-        for v in range(n):
+        if n:
             # straight into the receiving buffer (with gloo the exchange is staged through the host)
-            _all_to_all(work[v], world, device, out=got[v])
-        if n and after_exchange is not None:
-            after_exchange()
+            _all_to_all(flat_w[:n * length], world, device, out=flat_g[:n * length], host_wait=not stream_ordered)
+            if after_exchange is not None:
+                after_exchange()
 
 
 class ShardedProver:
     """One rank of a proof whose transforms are spread over the GPUs as well (zg16_hshard_*): this rank's key
-    shard (h cyclic, the other queries by point range), its stage object and its two exchange buffers."""
+    shard (h cyclic, the other queries by point range), its stage object and its two exchange buffers.
+
+    Over RCCL the whole proof is stream-ordered: the library queues its main-stream work on a torch stream of this
+    object's, the three all-to-alls are queued on that same stream between the stages (RCCL's own stream waits for
+    it and it waits for RCCL's, on the GPU), and the host waits once, for the results.  Over gloo (the one-GPU
+    rehearsal) every exchange is staged through the host."""
 
     def __init__(self, ctx, params, mat, rank, world, device):
         import torch
+        import torch.distributed as dist
         self.ctx, self.mat, self.rank, self.world, self.device = ctx, mat, rank, world, device
         self.log_g = world.bit_length() - 1
         assert 1 << self.log_g == world and 2 <= world <= 8, "2, 4 or 8 ranks"
@@ -157,9 +184,16 @@ class ShardedProver:
         self.rows = L.zg16_hshard_vector_bytes(self.hs) // 32
         self.work = torch.empty((3, self.rows, 4), dtype=torch.int64, device=device)
         self.got = torch.empty((3, self.rows, 4), dtype=torch.int64, device=device)
+        self.stream = None
+        if dist.get_backend() != "gloo" and device is not None and device.type == "cuda":
+            self.stream = torch.cuda.Stream(device)
+            torch.cuda.synchronize(device)
+            ctx.set_stream(self.stream.cuda_stream)
+            _check(ctx.handle, L.zg16_hshard_stream_ordered(self.hs, 1))
 
     def prove(self, z_in_ptr, z_aux_ptr, on_device, r_mont, s_mont):
         """Returns the lib.Proof on rank 0 and None elsewhere."""
+        import contextlib
         import torch
         L = self.ctx._lib
 
@@ -170,12 +204,16 @@ class ShardedProver:
                                                         C.c_void_p(self.got.data_ptr()), C.byref(n)))
             return n.value
 
-        # the library's kernels run on its own streams: torch's copies must have landed before the next stage
-        run_sharded_stages(stage, self.work, self.got, self.world, self.device,
-                           after_exchange=lambda: torch.cuda.synchronize(self.device))
-        part = _lib.Partial()
-        _check(self.ctx.handle, L.zg16_hshard_finish(self.hs, C.byref(part)))
-        parts = gather_partials(part, self.world, self.rank, self.device)
+        ordered = self.stream is not None
+        with torch.cuda.stream(self.stream) if ordered else contextlib.nullcontext():
+            # staged (gloo): the library's kernels run on its own streams, so torch's copies must have landed before
+            # the next stage; ordered (RCCL): everything is on self.stream
+            run_sharded_stages(stage, self.work, self.got, self.world, self.device,
+                               after_exchange=None if ordered else (lambda: torch.cuda.synchronize(self.device)),
+                               stream_ordered=ordered)
+            part = _lib.Partial()
+            _check(self.ctx.handle, L.zg16_hshard_finish(self.hs, C.byref(part)))
+            parts = gather_partials(part, self.world, self.rank, self.device)
         if self.rank != 0:
             return None
         return finish(self.pk_view, parts, self.world, r_mont, s_mont)
@@ -188,6 +226,9 @@ class ShardedProver:
         if self.key:
             L.zg16_pk_free(self.key)
             self.key = C.c_void_p()
+        if self.stream is not None:
+            self.ctx.set_stream(None)
+            self.stream = None
 
 
 # ---- one transform over several GPUs --------------------------------------------------------------
@@ -208,11 +249,12 @@ def ntt_shard_output_index(n, rank, world):
     return (rank * blk + i + length * k1).reshape(-1)
 
 
-def _all_to_all(t, world, device, out=None):
+def _all_to_all(t, world, device, out=None, host_wait=True):
     """Equal-split all-to-all of a (L, 4) int64 tensor: chunk h goes to rank h, which stores what it
     gets from rank g at chunk g.  RCCL moves device memory; with gloo (CPU rehearsal) the data is staged
     through the host.  out: a tensor of the same shape to receive into (a different one from t); without it the
-    result is a new tensor (RCCL) or t itself (gloo)."""
+    result is a new tensor (RCCL) or t itself (gloo).  host_wait = False (RCCL only): the caller's next work is
+    queued on torch's current stream, which the collective already orders -- no wait on the host."""
     import torch
     import torch.distributed as dist
     staged = dist.get_backend() == "gloo"
@@ -236,8 +278,9 @@ def _all_to_all(t, world, device, out=None):
         res = t if out is None else out
         res.copy_(dst)
         return res
-    # RCCL's wait() orders only torch's current stream; the library works on its own streams
-    torch.cuda.current_stream(device).synchronize()
+    # RCCL's wait() orders only torch's current stream; unless the library works on that stream too, wait here
+    if host_wait:
+        torch.cuda.current_stream(device).synchronize()
     return dst
 
 

@@ -69,6 +69,7 @@ class Context:
             pass
 
     def set_stream(self, hip_stream):
+        """zg16_ctx_set_stream: a hipStream_t as an integer (e.g. torch.cuda.Stream.cuda_stream), None = the context's own."""
         _check(self.handle, self._lib.zg16_ctx_set_stream(self.handle, C.c_void_p(hip_stream)))
 
     def timings(self):

@@ -132,6 +132,7 @@ SYMBOLS = [
     ("zg16_hshard_vector_bytes", C.c_size_t, [C.c_void_p]),
     ("zg16_hshard_stage", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                     C.POINTER(C.c_int)]),
+    ("zg16_hshard_stream_ordered", C.c_int, [C.c_void_p, C.c_int]),
     ("zg16_hshard_finish", C.c_int, [C.c_void_p, C.POINTER(Partial)]),
     ("zg16_multi_create", C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
     ("zg16_multi_destroy", None, [C.c_void_p]),
