@@ -105,6 +105,11 @@ void        zg16_ctx_destroy(zg16_ctx* ctx);
 const char* zg16_last_error(const zg16_ctx* ctx);
 /* Make the context issue its work on a caller-owned hipStream_t (NULL = its own stream). */
 zg16_status zg16_ctx_set_stream(zg16_ctx* ctx, void* hip_stream);
+/* The hipStream_t the context issues its main-stream work on (its own unless zg16_ctx_set_stream changed it), so that
+ * a caller can queue its own work -- an RCCL collective between two stages of a sharded proof -- in order with the
+ * library's WITHOUT bringing a stream of its own: a GPU process has few hardware queues (4 by default), the context
+ * already uses four streams, and a fifth stream shares a queue with one of them and serialises behind it. */
+zg16_status zg16_ctx_get_stream(const zg16_ctx* ctx, void** hip_stream);
 
 /* ---- proving key -------------------------------------------------------------------------- */
 /* Upload the slice [shard_index/shard_count] of every query (contiguous point ranges) so that

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--log-rows", type=int, default=20)
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--schedule", choices=("replicated", "sharded"), default="replicated")
+    ap.add_argument("--ranks", type=int, nargs="*", default=None, help="rank counts to time (default: all)")
     args = ap.parse_args()
     import torch
     torch.cuda.set_device(0)
@@ -43,7 +44,7 @@ def main():
     za_d = torch.from_numpy(za.view(np.int64)).cuda()
     if args.schedule == "sharded":
         return sharded(args, ctx, params, mat, zi_d, za_d)
-    for n in (1, 2, 4, 8):
+    for n in (args.ranks or (1, 2, 4, 8)):
         key = params.upload(ctx, 0, n)
         part = zlib.Partial()
 
@@ -67,8 +68,8 @@ def sharded(args, ctx, params, mat, zi_d, za_d):
     from zinc_amd import lib as zlib
     from zinc_amd.groth16 import _check
     L = ctx._lib
-    stream = torch.cuda.Stream()
-    for n in (2, 4, 8):
+    stream = torch.cuda.ExternalStream(ctx.get_stream())   # the context's own main stream, as over RCCL
+    for n in (args.ranks or (2, 4, 8)):
         log_g = n.bit_length() - 1
         view = params.view()
         key, hs = C.c_void_p(), C.c_void_p()
@@ -78,7 +79,6 @@ def sharded(args, ctx, params, mat, zi_d, za_d):
         work = torch.zeros((3 * rows, 4), dtype=torch.int64, device="cuda")
         got = torch.zeros((3 * rows, 4), dtype=torch.int64, device="cuda")
         torch.cuda.synchronize()
-        ctx.set_stream(stream.cuda_stream)
         _check(ctx.handle, L.zg16_hshard_stream_ordered(hs, 1))
         part = zlib.Partial()
 
@@ -100,7 +100,6 @@ def sharded(args, ctx, params, mat, zi_d, za_d):
         torch.cuda.synchronize()
         ms = 1e3 * (time.perf_counter() - t0) / args.reps
         print("ranks %d, sharded schedule: shard 0 alone %.3f ms per proof (exchanges as device copies)" % (n, ms), flush=True)
-        ctx.set_stream(None)
         L.zg16_hshard_free(hs)
         L.zg16_pk_free(key)
 

@@ -228,6 +228,12 @@ zg16_status zg16_ctx_set_stream(zg16_ctx* ctx, void* hip_stream) {
   return ZG16_OK;
 }
 
+zg16_status zg16_ctx_get_stream(const zg16_ctx* ctx, void** hip_stream) {
+  if (!ctx || !hip_stream) return ZG16_ERR_INVALID_ARGUMENT;
+  *hip_stream = (void*)ctx->stream;
+  return ZG16_OK;
+}
+
 // ---------------------------------------------------------------------------------- proving key
 zg16_status zg16_pk_upload(zg16_ctx* ctx, const zg16_pk_view* v, int shard_index, int shard_count, zg16_pk** out) {
   return zg::pk_upload_impl(ctx, v, shard_index, shard_count, false, out);

@@ -164,10 +164,11 @@ class ShardedProver:
     """One rank of a proof whose transforms are spread over the GPUs as well (zg16_hshard_*): this rank's key
     shard (h cyclic, the other queries by point range), its stage object and its two exchange buffers.
 
-    Over RCCL the whole proof is stream-ordered: the library queues its main-stream work on a torch stream of this
-    object's, the three all-to-alls are queued on that same stream between the stages (RCCL's own stream waits for
-    it and it waits for RCCL's, on the GPU), and the host waits once, for the results.  Over gloo (the one-GPU
-    rehearsal) every exchange is staged through the host."""
+    Over RCCL the whole proof is stream-ordered: torch is handed the context's own main stream (no new stream: a
+    process has few hardware queues and a fifth stream would serialise behind one of the context's four), the
+    three all-to-alls are queued on it between the stages (RCCL's own stream waits for it and it waits for RCCL's,
+    on the GPU), and the host waits once, for the results.  Over gloo (the one-GPU rehearsal) every exchange is
+    staged through the host."""
 
     def __init__(self, ctx, params, mat, rank, world, device):
         import torch
@@ -186,9 +187,7 @@ class ShardedProver:
         self.got = torch.empty((3, self.rows, 4), dtype=torch.int64, device=device)
         self.stream = None
         if dist.get_backend() != "gloo" and device is not None and device.type == "cuda":
-            self.stream = torch.cuda.Stream(device)
-            torch.cuda.synchronize(device)
-            ctx.set_stream(self.stream.cuda_stream)
+            self.stream = torch.cuda.ExternalStream(ctx.get_stream(), device=device)
             _check(ctx.handle, L.zg16_hshard_stream_ordered(self.hs, 1))
 
     def prove(self, z_in_ptr, z_aux_ptr, on_device, r_mont, s_mont):
@@ -226,9 +225,7 @@ class ShardedProver:
         if self.key:
             L.zg16_pk_free(self.key)
             self.key = C.c_void_p()
-        if self.stream is not None:
-            self.ctx.set_stream(None)
-            self.stream = None
+        self.stream = None
 
 
 # ---- one transform over several GPUs --------------------------------------------------------------

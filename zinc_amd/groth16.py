@@ -72,6 +72,12 @@ class Context:
         """zg16_ctx_set_stream: a hipStream_t as an integer (e.g. torch.cuda.Stream.cuda_stream), None = the context's own."""
         _check(self.handle, self._lib.zg16_ctx_set_stream(self.handle, C.c_void_p(hip_stream)))
 
+    def get_stream(self):
+        """zg16_ctx_get_stream: the hipStream_t of the context's main-stream work, as an integer."""
+        out = C.c_void_p()
+        _check(self.handle, self._lib.zg16_ctx_get_stream(self.handle, C.byref(out)))
+        return out.value or 0
+
     def timings(self):
         t = _lib.Timings()
         _check(self.handle, self._lib.zg16_last_timings(self.handle, C.byref(t)))

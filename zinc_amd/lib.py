@@ -89,6 +89,7 @@ SYMBOLS = [
     ("zg16_ctx_destroy", None, [C.c_void_p]),
     ("zg16_last_error", C.c_char_p, [C.c_void_p]),
     ("zg16_ctx_set_stream", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("zg16_ctx_get_stream", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     ("zg16_pk_upload", C.c_int, [C.c_void_p, C.POINTER(PkView), C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     ("zg16_pk_free", None, [C.c_void_p]),
     ("zg16_pk_upload_bytes", C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
