@@ -436,7 +436,10 @@ zg16_status zg16_last_timings(const zg16_ctx* ctx, zg16_timings* out);
  * field: 0 Fr, 1 Fq, 2 Fq2.  op: 0 add, 1 sub, 2 mul, 3 square, 4 negate, 5 inverse (0 -> 0).
  * group: 1 G1, 2 G2 (saturated 32-bit-limb code: key tables, host assembly); 3 G1, 4 G2 through the
  * arithmetic of the multiexp kernels (29-bit-limb field; G2 values spread over lane pairs).
- * op: 0 double p, 1 p + q (mixed), 2 p + q (projective), 3 k * p with k a Montgomery Fr.
+ * op: 0 double p, 1 p + q (mixed), 2 p + q (projective), 3 k * p with k a Montgomery Fr; group 4 only (q unused):
+ * 4 [6 x^2] p and 5 psi(p), the two sides of the subgroup test the key-file decoder runs on every b_g2 point
+ * (x the BN parameter, psi the untwist-Frobenius-twist map); 6 the decoder's own kernel on each point: the first
+ * limb of out[i] is 1 when it accepts p[i], else 0.
  * Inputs and outputs are affine points / Montgomery limbs in host memory. */
 zg16_status zg16_selftest_field(zg16_ctx* ctx, int field, int op, const uint64_t* a, const uint64_t* b,
                                 size_t n, uint64_t* out);

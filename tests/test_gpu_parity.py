@@ -88,6 +88,50 @@ def test_group_ops_golden(gpu_ctx, name, group):
     assert run(3, pts, ks) == [unhex(c["out"]) for c in sm["cases"]]
 
 
+def test_g2_subgroup_test_sides(gpu_ctx):
+    """The subgroup test the key-file decoder runs on every b_g2 point, psi(P) = [6 x^2] P (psi the
+    untwist-Frobenius-twist map, x the BN parameter), side by side in the lane-pair arithmetic: both sides equal the
+    oracle's big-integer values on points of G2 (where they agree with each other) and on a twist point outside
+    G2 (where they differ) -- the accept set is that of r P = O."""
+    from oracle import bn254 as B
+    from zinc_amd import codec
+    fx = golden("g2_ops.json")
+    pts = [unhex(c["p"]) for c in fx["cases"] if unhex(c["p"]) is not None]
+    pts += [p for i in (1, 2, 3) for p in FixtureKey(golden("prove_tiny_%d.json" % i)).b_g2]
+    x = (5, 1)
+    while True:     # a point of the twist whose order is not r
+        rhs = codec._fq2_mul(codec._fq2_mul(x, x), x)
+        y = codec._fq2_sqrt(((rhs[0] + codec.B_G2[0]) % Q_MOD, (rhs[1] + codec.B_G2[1]) % Q_MOD))
+        if y is not None and not codec._g2_times_order_is_identity((x, y)):
+            break
+        x = (x[0] + 1, 1)
+    off = (x, y)
+    pts.append(off)
+    bn_x = 4965661367192848881
+    k = 6 * bn_x * bn_x
+    assert k == Q_MOD - R_MOD
+    xi = (9, 1)
+    kx, ky = codec._fq2_pow(xi, (Q_MOD - 1) // 3), codec._fq2_pow(xi, (Q_MOD - 1) // 2)
+    conj = lambda a: (a[0], (-a[1]) % Q_MOD)
+    psi = lambda p: (codec._fq2_mul(conj(p[0]), kx), codec._fq2_mul(conj(p[1]), ky))
+
+    def run(op):
+        arr = np.ascontiguousarray(g2_to_mont(pts), dtype=np.uint64)
+        out = np.zeros_like(arr)
+        st = gpu_ctx._lib.zg16_selftest_group(gpu_ctx.handle, 4, op, zlib.as_u64p(arr), None, arr.shape[0], zlib.as_u64p(out))
+        assert st == 0
+        return mont_to_g2(out)
+
+    arr = np.ascontiguousarray(g2_to_mont(pts), dtype=np.uint64)
+    verdict = np.zeros_like(arr)
+    assert gpu_ctx._lib.zg16_selftest_group(gpu_ctx.handle, 4, 6, zlib.as_u64p(arr), None, arr.shape[0], zlib.as_u64p(verdict)) == 0
+    assert [int(v) for v in verdict[:, 0]] == [1] * (len(pts) - 1) + [0]
+    times, frob = run(4), run(5)
+    assert frob == [psi(p) for p in pts]
+    assert times == [B.G2.to_affine(B.G2.mul(B.G2.from_affine(p), k)) for p in pts]
+    assert times[:-1] == frob[:-1] and times[-1] != frob[-1]
+
+
 # ------------------------------------------------------------------------------ NTT / H
 @pytest.mark.parametrize("log_n", [4, 5, 6, 7, 8, 9, 10])
 def test_ntt_golden(gpu_ctx, log_n):

@@ -399,3 +399,22 @@ def test_gloo_sharded_h_schedule(world):
             raise
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert "HSHARD_MATCH" in outs[0], outs[0]
+
+
+def test_key_file_encoder_matches_codec():
+    """workload.params_file_bytes (the threaded encoder benchmarks make 0.4 .. 6 GB key files with) writes what the
+    point-by-point codec -- and the oracle's restatement of Parameters::write -- writes."""
+    from oracle import codec as ocodec
+    from zinc_amd import workload
+    from zinc_amd.fields import g1_to_mont, g2_to_mont
+    from zinc_amd.groth16 import Parameters
+    for idx in (1, 2, 3):
+        k = FixtureKey(golden("prove_tiny_%d.json" % idx))
+        p = Parameters.from_points(k)
+        p.gamma_g2, p.ic = g2_to_mont([k.gamma_g2]), g1_to_mont(k.ic)
+        data = bytes(workload.params_file_bytes(p, threads=3))
+        assert data == codec.params_write(k) == ocodec.params_bytes(k)
+    k.h[1] = None   # the identity inside a vector: 0x40 and zeros
+    p = Parameters.from_points(k)
+    p.gamma_g2, p.ic = g2_to_mont([k.gamma_g2]), g1_to_mont(k.ic)
+    assert bytes(workload.params_file_bytes(p)) == codec.params_write(k)

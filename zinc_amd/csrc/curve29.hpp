@@ -233,6 +233,42 @@ ZG_D void add_full_pair(XYZZ29<P>& acc, const XYZZ29<P>& p) {
   acc.zzz = mul_pair(mul_pair(acc.zzz, p.zzz, P::KS2), ppp, P::KS2);
 }
 
+// ---- the two sides of the G2 subgroup test psi(P) = [6x^2] P (see g2_in_subgroup in curve.hpp), on a lane pair ----
+// [6 x^2] P for an affine, non-identity P; 6 x^2 = 0x6f4d8248eeb859fb f83e9682e87cfd46 (127 bits), x the BN parameter.
+template <class P>
+ZG_D XYZZ29<P> g2_times_6x2_pair(const Affine29<P>& base) {
+  const uint64_t e_hi = 0x6f4d8248eeb859fbull, e_lo = 0xf83e9682e87cfd46ull;
+  XYZZ29<P> acc = XYZZ29<P>::inf();
+  add_mixed_pair(acc, base);  // bit 126
+#pragma unroll 1
+  for (int bit = 125; bit >= 0; bit--) {
+    acc = dbl_pair(acc);
+    if (((bit < 64 ? e_lo >> bit : e_hi >> (bit - 64)) & 1) != 0) add_mixed_pair(acc, base);
+  }
+  return acc;
+}
+// psi(P) = (conj(x) kx, conj(y) ky) with (kx, ky) this lane's components of xi^((q-1)/3), xi^((q-1)/2) (canonical,
+// radix-2^261 Montgomery form); components below 2p with normalised limbs.
+template <class P>
+ZG_D Affine29<P> g2_psi_pair(const Affine29<P>& base, const Fp29<P>& kx, const Fp29<P>& ky) {
+  using F = Fp29<P>;
+  const bool im = (threadIdx.x & 1) != 0;
+  const F cx = im ? sub_k(F::zero(), base.x, P::K2) : base.x;   // conj: the imaginary lane holds 2p - x1
+  const F cy = im ? sub_k(F::zero(), base.y, P::K2) : base.y;
+  return {mul_pair(cx, kx, P::KS2), mul_pair(cy, ky, P::KS2)};   // 2 * (1 + 2)
+}
+// Is the point (X / ZZ, Y / ZZZ) of acc (not the identity) the affine point q (components below 2p)?
+template <class P>
+ZG_D bool pair_equals_affine(const XYZZ29<P>& acc, const Affine29<P>& q) {
+  using F = Fp29<P>;
+  const F dx = sub_k(mul_pair(acc.zz, q.x, P::KS3), acc.x, P::K6);    // 2 * (2 + 3); X < 6p; < 8p
+  const F dy = sub_k(mul_pair(acc.zzz, q.y, P::KS3), acc.y, P::K4);   // Y < 4p; < 6p
+  const F one = pair_one<P>();
+  // a product by one brings the differences below 2p with strictly normalised limbs, where zero is 0 or p
+  const bool zx = is_zero_mod_p(mul_pair(dx, one, P::KS2)), zy = is_zero_mod_p(mul_pair(dy, one, P::KS2));  // 8 * (1 + 2)
+  return pair_both(zx && zy);
+}
+
 // ---- memory formats -------------------------------------------------------------------------
 // Packed affine base (x || y, 8 x 32-bit words each, canonical, radix-2^261 Montgomery form).
 template <class P, class Q>

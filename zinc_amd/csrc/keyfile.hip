@@ -21,6 +21,7 @@
 
 #define ZG_OUTLINE_FIELD_MUL 1
 #include "r1cs.hpp"
+#include "msm_ops.hpp"
 
 namespace zg {
 
@@ -64,6 +65,8 @@ ZG_HD uint32_t decode_g1(const uint8_t* b, bool checked, bool allow_inf, Affine<
 // r, the group order, little-endian words
 ZG_HD uint32_t order_word(int i) { return FrParams::mod(i); }
 
+// checked: 0 none; 1 on the twist and in the subgroup (psi test); 2 the same with the plain r P = O; 3 on the twist
+// only (the caller runs the subgroup test in its own kernel, k_g2_subgroup)
 ZG_HD uint32_t decode_g2(const uint8_t* b, int checked, bool allow_inf, const G2SubgroupConsts& k, Affine<Fq2>* out) {
   *out = Affine<Fq2>::inf();
   if (b[0] & 0x80) return DEC_ENCODING;
@@ -81,7 +84,7 @@ ZG_HD uint32_t decode_g2(const uint8_t* b, int checked, bool allow_inf, const G2
       uint32_t r[8];
       for (int i = 0; i < 8; i++) r[i] = order_word(i);
       if (!scalar_mul(XYZZ<Fq2>::from_affine(p), r).is_inf()) return DEC_NOT_IN_SUBGROUP;
-    } else if (!g2_in_subgroup(p, k)) {
+    } else if (checked == 1 && !g2_in_subgroup(p, k)) {
       return DEC_NOT_IN_SUBGROUP;
     }
   }
@@ -107,6 +110,34 @@ __global__ __launch_bounds__(256, 1) void k_decode_g2(const uint8_t* __restrict_
   const uint32_t e = decode_g2(src + (size_t)i * 128, checked, false, curve_b, &p);
   dst[i] = p;
   if (e) atomicMax(err, e);
+}
+
+// The subgroup test of g2_in_subgroup -- psi(P) = [6x^2] P -- for a whole query vector, in the arithmetic of the
+// multiexp kernels: a lane pair per point (even lane: real components, odd lane: imaginary ones), 29-bit limbs,
+// three waves per SIMD, where the element-wise form above is one lane per point in saturated limbs at one wave per
+// SIMD.  pts: decoded points in the ABI form (the identity is skipped: the decoder has already judged it).
+// psi: the constants (psi_x, psi_y) of G2SubgroupConsts as one "point" in the multiexp kernels' packed form.
+__global__ __launch_bounds__(256, 2) void k_g2_subgroup(const Affine<Fq2>* __restrict__ pts, uint32_t n,
+                                                        const Affine<Fq2>* __restrict__ psi, uint32_t* __restrict__ err) {
+  using O = MsmOps<Fq2>;
+  using P = Fq29Params;
+  const uint32_t j = (blockIdx.x * blockDim.x + threadIdx.x) / 2;
+  if (j >= n) return;  // (the lanes of a pair share j)
+  const int im = O::sub();
+  const Fq* c = (const Fq*)(pts + j);
+  const Fq x = c[im], y = c[2 + im];
+  if (pair_both(x.is_zero() && y.is_zero())) return;
+  // ABI form (Montgomery radix 2^256) -> the 29-bit code's radix 2^261, canonical as a stored base is: one product
+  // and a conditional subtraction.  (Five modular doublings of the packed words, the way the table builder converts,
+  // are compiled into a loop over partly overlapping vector loads here that corrupts words of the value: hipcc 7.2.)
+  const O::Aff base = {unpack29<P>(pack29<P, FqParams>(from_r256<P>(x))), unpack29<P>(pack29<P, FqParams>(from_r256<P>(y)))};
+  O::Aff k;
+  O::load_base(psi, false, &k);
+  const O::Pt acc = g2_times_6x2_pair(base);
+  // the identity is not psi(P), which is a finite point
+  const bool inf = O::is_inf(acc);
+  const bool eq = pair_equals_affine(acc, g2_psi_pair(base, k.x, k.y));
+  if ((inf || !eq) && !im) atomicMax(err, (uint32_t)DEC_NOT_IN_SUBGROUP);
 }
 
 static const char* decode_text(uint32_t e) {
@@ -146,36 +177,44 @@ static zg16_status query_tables(zg16_ctx* ctx, Affine<F>* pts, size_t count, uin
   return msm_build_table<F>(ctx, pts, count, table_c, table_step);
 }
 
-// Decode points [lo, hi) of a vector of `point_bytes`-byte encodings into window 0 of a fresh table and
-// fill the other windows.
+// The packed-form psi constants k_g2_subgroup takes (the ABI values times 32), at an address that outlives any copy.
+static const Affine<Fq2>* psi_consts_internal() {
+  static const Affine<Fq2> packed = MsmOps<Fq2>::to_internal(Affine<Fq2>{g2_subgroup_consts().psi_x, g2_subgroup_consts().psi_y});
+  return &packed;
+}
+
+// Queue, on `st`, the copy of points [lo, hi) of a vector of encodings to the GPU and their decoding into window 0
+// of a fresh table (*dst, allocated here with room for every window), with the checks `checked` asks for.  Nothing
+// waits: a violation raises the flag *err (device memory, one word per query, cleared by the caller) and the caller
+// reads the flags once everything is queued.  raw: device scratch for the encodings (count * sizeof(Affine<F>) bytes
+// rounded up to 256, and 256 more).
 template <class F>
-static zg16_status decode_query(zg16_ctx* ctx, const uint8_t* bytes, size_t lo, size_t hi, int checked, uint32_t table_c,
-                                uint32_t table_step, const G2SubgroupConsts& curve_b, const char* name, Affine<F>** dst,
-                                Affine<F>** direct, bool build_tables) {
+static zg16_status decode_enqueue(zg16_ctx* ctx, hipStream_t st, const uint8_t* bytes, size_t lo, size_t hi, int checked,
+                                  uint32_t table_c, uint32_t table_step, const G2SubgroupConsts& consts, uint8_t* raw,
+                                  uint32_t* err, Affine<F>** dst) {
   *dst = nullptr;
-  *direct = nullptr;
   const size_t count = hi - lo;
   if (!count) return ZG16_OK;
   constexpr size_t PB = sizeof(Affine<F>);  // the encoding is as long as the affine point
   const size_t windows = table_c ? msm_table_windows(table_c, table_step) : 1;
   ZG_HIP(ctx, hipMalloc((void**)dst, windows * count * sizeof(Affine<F>)));
-  uint8_t* raw;
-  ZG_TRY(scratch_get(ctx, 5, count * PB + 256, (void**)&raw));
-  uint32_t* err;
-  ZG_TRY(scratch_get(ctx, 7, 256, (void**)&err));
-  ZG_HIP(ctx, hipMemsetAsync(err, 0, 4, ctx->stream));
-  ZG_HIP(ctx, hipMemcpyAsync(raw, bytes + lo * PB, count * PB, hipMemcpyHostToDevice, ctx->stream));
+  ZG_HIP(ctx, hipMemcpyAsync(raw, bytes + lo * PB, count * PB, hipMemcpyHostToDevice, st));
   const unsigned grid = (unsigned)((count + 255) / 256);
-  if constexpr (sizeof(F) == sizeof(Fq))
-    k_decode_g1<<<grid, 256, 0, ctx->stream>>>(raw, (uint32_t)count, checked, *dst, err);
-  else
-    k_decode_g2<<<grid, 256, 0, ctx->stream>>>(raw, (uint32_t)count, checked, curve_b, *dst, err);
+  if constexpr (sizeof(F) == sizeof(Fq)) {
+    k_decode_g1<<<grid, 256, 0, st>>>(raw, (uint32_t)count, checked, *dst, err);
+  } else {
+    // checked = 1: on the twist in the decoder, the subgroup test in the lane-pair kernel; 2: the plain r P = O
+    // inside the decoder (the slow form, kept as the checker of the other)
+    k_decode_g2<<<grid, 256, 0, st>>>(raw, (uint32_t)count, checked == 1 ? 3 : checked, consts, *dst, err);
+    if (checked == 1) {
+      // (the constants ride in the slack behind the encodings)
+      Affine<Fq2>* psi = (Affine<Fq2>*)(raw + ((count * PB + 255) & ~(size_t)255));
+      ZG_HIP(ctx, hipMemcpyAsync(psi, psi_consts_internal(), sizeof(Affine<Fq2>), hipMemcpyHostToDevice, st));
+      k_g2_subgroup<<<(unsigned)((2 * count + 255) / 256), 256, 0, st>>>(*dst, (uint32_t)count, psi, err);
+    }
+  }
   ZG_HIP(ctx, hipGetLastError());
-  uint32_t herr = 0;
-  ZG_HIP(ctx, hipMemcpyAsync(&herr, err, 4, hipMemcpyDeviceToHost, ctx->stream));
-  ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (herr) return fail(ctx, ZG16_ERR_MALFORMED_KEY, "%s query: %s", name, decode_text(herr));
-  return build_tables ? query_tables<F>(ctx, *dst, count, table_c, table_step, direct) : ZG16_OK;
+  return ZG16_OK;
 }
 
 }  // namespace zg
@@ -258,42 +297,75 @@ zg16_status zg16_pk_upload_bytes(zg16_ctx* ctx, const uint8_t* data, size_t len,
                               {pk->hi_b - pk->lo_b, pk->table_c_g2, 128}};
     pk->table_step = msm_table_step(tq, 5);
   }
-  // Small keys: decode the five queries, then build their tables side by side on the context's four streams (each
-  // is a chain of short kernels on a handful of wavefronts); large keys fill the GPU one query at a time.
+  // Two chains side by side.  The copy / decode / check chain runs on the context's second stream in the order h, l,
+  // a, b_g1, b_g2 and records an event behind each query; the table builders follow on the main stream (small keys:
+  // on all four streams, each query's chain of short kernels beside the others'), each behind its query's event.  So
+  // the PCIe copy and the checks of the later queries -- the G2 subgroup test is the longest -- hide under the table
+  // expansion of the earlier ones, and the host waits once, at the end.
   size_t most = pk->hi_h - pk->lo_h;
   for (size_t q : {pk->hi_l - pk->lo_l, pk->hi_a - pk->lo_a, pk->hi_b - pk->lo_b}) most = q > most ? q : most;
   const bool side_by_side = most <= ((size_t)1 << 16) && ctx->stream == ctx->own_stream && !ctx->deferred_frees;
-  const bool now = !side_by_side;
-  ZG_TRY(decode_query<Fq>(ctx, vec[0], pk->lo_h, pk->hi_h, checked, pk->table_c_h, pk->table_step, curve_b, names[0], &pk->h, &pk->h_d, now));
-  ZG_TRY(decode_query<Fq>(ctx, vec[1], pk->lo_l, pk->hi_l, checked, pk->table_c, pk->table_step, curve_b, names[1], &pk->l, &pk->l_d, now));
-  ZG_TRY(decode_query<Fq>(ctx, vec[2], pk->lo_a, pk->hi_a, checked, pk->table_c, pk->table_step, curve_b, names[2], &pk->a, &pk->a_d, now));
-  ZG_TRY(decode_query<Fq>(ctx, vec[3], pk->lo_b, pk->hi_b, checked, pk->table_c, pk->table_step, curve_b, names[3], &pk->b1, &pk->b1_d, now));
-  ZG_TRY(decode_query<Fq2>(ctx, vec[4], pk->lo_b, pk->hi_b, checked, pk->table_c_g2, pk->table_step, curve_b, names[4], &pk->b2, &pk->b2_d, now));
-  if (side_by_side) {
-    std::vector<void*> scratch_to_free;
-    hipStream_t const own = ctx->stream;
-    auto build_all = [&]() -> zg16_status {
-      ctx->stream = ctx->aux_stream;
-      ZG_TRY(query_tables<Fq2>(ctx, pk->b2, pk->hi_b - pk->lo_b, pk->table_c_g2, pk->table_step, &pk->b2_d));
-      ctx->stream = own;
-      ZG_TRY(query_tables<Fq>(ctx, pk->h, pk->hi_h - pk->lo_h, pk->table_c_h, pk->table_step, &pk->h_d));
-      ctx->stream = ctx->early_stream;
-      ZG_TRY(query_tables<Fq>(ctx, pk->l, pk->hi_l - pk->lo_l, pk->table_c, pk->table_step, &pk->l_d));
-      ctx->stream = ctx->side_stream;
-      ZG_TRY(query_tables<Fq>(ctx, pk->a, pk->hi_a - pk->lo_a, pk->table_c, pk->table_step, &pk->a_d));
-      ctx->stream = own;
-      ZG_TRY(query_tables<Fq>(ctx, pk->b1, pk->hi_b - pk->lo_b, pk->table_c, pk->table_step, &pk->b1_d));
+  const size_t cnt_q[5] = {pk->hi_h - pk->lo_h, pk->hi_l - pk->lo_l, pk->hi_a - pk->lo_a, pk->hi_b - pk->lo_b, pk->hi_b - pk->lo_b};
+  const size_t lo_q[5] = {pk->lo_h, pk->lo_l, pk->lo_a, pk->lo_b, pk->lo_b};
+  size_t raw_off[6] = {0};
+  for (int k = 0; k < 5; k++) raw_off[k + 1] = raw_off[k] + ((cnt_q[k] * (k == 4 ? 128 : 64) + 255) & ~(size_t)255) + 256;
+  uint8_t* raw = nullptr;
+  uint32_t* err = nullptr;
+  hipEvent_t decoded[5] = {};
+  std::vector<void*> scratch_to_free;
+  hipStream_t const own = ctx->stream;
+  hipStream_t const feed = ctx->stream == ctx->own_stream ? ctx->aux_stream : ctx->stream;
+  auto run = [&]() -> zg16_status {
+    ZG_HIP(ctx, hipMalloc((void**)&raw, raw_off[5] + 256));
+    ZG_HIP(ctx, hipMalloc((void**)&err, 256));
+    ZG_HIP(ctx, hipMemsetAsync(err, 0, 256, feed));
+    for (auto& e : decoded) ZG_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    // the builders are queued without waiting (their scratch is freed below, after the streams have drained), each
+    // right behind its own query's decoding: a copy from pageable memory holds the host until it is staged, so the
+    // tables of query k are already being built while the host feeds query k + 1
+    auto on = [&](hipStream_t s, int k) -> zg16_status {
+      ZG_HIP(ctx, hipEventRecord(decoded[k], feed));
+      ctx->stream = side_by_side ? s : own;
+      ZG_HIP(ctx, hipStreamWaitEvent(ctx->stream, decoded[k], 0));
       return ZG16_OK;
     };
-    ctx->deferred_frees = &scratch_to_free;
-    const zg16_status built = build_all();
-    ctx->stream = own;
-    ctx->deferred_frees = nullptr;
-    const hipError_t drained = hipDeviceSynchronize();  // also after a failure: the scratch is in use until then
-    for (void* p : scratch_to_free) (void)hipFree(p);
-    ZG_TRY(built);
-    ZG_HIP(ctx, drained);
-  }
+    ZG_TRY(decode_enqueue<Fq>(ctx, feed, vec[0], lo_q[0], lo_q[0] + cnt_q[0], checked, pk->table_c_h, pk->table_step, curve_b, raw + raw_off[0], err + 0, &pk->h));
+    ZG_TRY(on(own, 0));
+    ZG_TRY(query_tables<Fq>(ctx, pk->h, cnt_q[0], pk->table_c_h, pk->table_step, &pk->h_d));
+    ZG_TRY(decode_enqueue<Fq>(ctx, feed, vec[1], lo_q[1], lo_q[1] + cnt_q[1], checked, pk->table_c, pk->table_step, curve_b, raw + raw_off[1], err + 1, &pk->l));
+    ZG_TRY(on(ctx->early_stream, 1));
+    ZG_TRY(query_tables<Fq>(ctx, pk->l, cnt_q[1], pk->table_c, pk->table_step, &pk->l_d));
+    ZG_TRY(decode_enqueue<Fq>(ctx, feed, vec[2], lo_q[2], lo_q[2] + cnt_q[2], checked, pk->table_c, pk->table_step, curve_b, raw + raw_off[2], err + 2, &pk->a));
+    ZG_TRY(on(ctx->side_stream, 2));
+    ZG_TRY(query_tables<Fq>(ctx, pk->a, cnt_q[2], pk->table_c, pk->table_step, &pk->a_d));
+    ZG_TRY(decode_enqueue<Fq>(ctx, feed, vec[3], lo_q[3], lo_q[3] + cnt_q[3], checked, pk->table_c, pk->table_step, curve_b, raw + raw_off[3], err + 3, &pk->b1));
+    ZG_TRY(on(own, 3));
+    ZG_TRY(query_tables<Fq>(ctx, pk->b1, cnt_q[3], pk->table_c, pk->table_step, &pk->b1_d));
+    ZG_TRY(decode_enqueue<Fq2>(ctx, feed, vec[4], lo_q[4], lo_q[4] + cnt_q[4], checked, pk->table_c_g2, pk->table_step, curve_b, raw + raw_off[4], err + 4, &pk->b2));
+    ZG_TRY(on(feed, 4));
+    ZG_TRY(query_tables<Fq2>(ctx, pk->b2, cnt_q[4], pk->table_c_g2, pk->table_step, &pk->b2_d));
+    return ZG16_OK;
+  };
+  std::vector<void*>* const outer_frees = ctx->deferred_frees;
+  if (!outer_frees) ctx->deferred_frees = &scratch_to_free;
+  const zg16_status queued = run();
+  ctx->stream = own;
+  ctx->deferred_frees = outer_frees;
+  // every stream, also after a failure: the buffers below are in use until then
+  const hipError_t drained = hipDeviceSynchronize();
+  uint32_t herr[5] = {};
+  hipError_t read = hipSuccess;
+  if (err) read = hipMemcpy(herr, err, sizeof herr, hipMemcpyDeviceToHost);
+  for (void* p : scratch_to_free) (void)hipFree(p);
+  (void)hipFree(raw);
+  (void)hipFree(err);
+  for (auto& e : decoded)
+    if (e) (void)hipEventDestroy(e);
+  ZG_TRY(queued);
+  ZG_HIP(ctx, drained);
+  ZG_HIP(ctx, read);
+  for (int k = 0; k < 5; k++)
+    if (herr[k]) return fail(ctx, ZG16_ERR_MALFORMED_KEY, "%s query: %s", names[k], decode_text(herr[k]));
   *out = pk.release();
   return ZG16_OK;
 }

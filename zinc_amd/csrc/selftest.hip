@@ -86,6 +86,53 @@ __global__ __launch_bounds__(64) void k_group_op_msm(int op, const Affine<F>* p,
   O::store_std(out + i, acc);
 }
 
+// The two sides of the G2 subgroup test in the lane-pair arithmetic: op 4: [6x^2] P, op 5: psi(P) (q = the two psi
+// constants as one affine "point" (psi_x, psi_y) in the packed base form).
+__global__ __launch_bounds__(64) void k_g2_endo_msm(int op, const Affine<Fq2>* p, const Affine<Fq2>* consts, XYZZ<Fq2>* out, uint32_t n) {
+  using O = MsmOps<Fq2>;
+  const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) / 2;
+  if (i >= n) return;
+  O::Aff a, k;
+  O::Pt acc = O::inf();
+  if (O::load_base(p + i, false, &a)) {
+    if (op == 4) {
+      acc = g2_times_6x2_pair(a);
+    } else {
+      O::load_base(consts, false, &k);
+      const O::Aff q = g2_psi_pair(a, k.x, k.y);
+      acc = {q.x, q.y, pair_one<Fq29Params>(), pair_one<Fq29Params>()};
+      // the comparison the key decoder makes, exercised on the way: psi(P) must equal itself and differ from P
+      if (!pair_equals_affine(acc, q) || pair_equals_affine(acc, a)) acc = O::inf();
+    }
+  }
+  O::store_std(out + i, acc);
+}
+
+// keyfile.hip: the subgroup test as the key-file decoder launches it (points in the ABI form)
+__global__ void k_g2_subgroup(const Affine<Fq2>* __restrict__ pts, uint32_t n, const Affine<Fq2>* __restrict__ psi,
+                              uint32_t* __restrict__ err);
+
+// op 6: out[0] of every point = 1 when the decoder's kernel accepts the point alone, else 0 (one launch per point)
+static zg16_status run_g2_subgroup_kernel(zg16_ctx* ctx, const uint64_t* p, size_t n, uint64_t* out) {
+  char* buf;
+  ZG_TRY(scratch_get(ctx, 5, n * sizeof(Affine<Fq2>) + 512 + 4 * n, (void**)&buf));
+  Affine<Fq2>* psi = (Affine<Fq2>*)(buf + ((n * sizeof(Affine<Fq2>) + 255) & ~(size_t)255));
+  uint32_t* err = (uint32_t*)(psi + 2);
+  ZG_HIP(ctx, hipMemcpyAsync(buf, p, n * sizeof(Affine<Fq2>), hipMemcpyHostToDevice, ctx->stream));
+  ZG_HIP(ctx, hipMemsetAsync(err, 0, 4 * n, ctx->stream));
+  static const Affine<Fq2> k = MsmOps<Fq2>::to_internal(Affine<Fq2>{g2_subgroup_consts().psi_x, g2_subgroup_consts().psi_y});
+  ZG_HIP(ctx, hipMemcpyAsync(psi, &k, sizeof k, hipMemcpyHostToDevice, ctx->stream));
+  for (size_t i = 0; i < n; i++)
+    k_g2_subgroup<<<1, 256, 0, ctx->stream>>>((const Affine<Fq2>*)buf + i, 1, psi, err + i);
+  ZG_HIP(ctx, hipGetLastError());
+  std::vector<uint32_t> flags(n);
+  ZG_HIP(ctx, hipMemcpyAsync(flags.data(), err, 4 * n, hipMemcpyDeviceToHost, ctx->stream));
+  ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  memset(out, 0, n * sizeof(Affine<Fq2>));
+  for (size_t i = 0; i < n; i++) out[16 * i] = flags[i] ? 0 : 1;
+  return ZG16_OK;
+}
+
 template <class F>
 static zg16_status run_group_msm(zg16_ctx* ctx, int op, const uint64_t* p, const uint64_t* q, size_t n, uint64_t* out) {
   char* buf;
@@ -93,12 +140,24 @@ static zg16_status run_group_msm(zg16_ctx* ctx, int op, const uint64_t* p, const
   const size_t pa = (pb + 255) & ~(size_t)255, qa = (qb + 255) & ~(size_t)255;
   ZG_TRY(scratch_get(ctx, 5, pa + qa + ob + 256, (void**)&buf));
   ZG_HIP(ctx, hipMemcpyAsync(buf, p, pb, hipMemcpyHostToDevice, ctx->stream));
-  if (op != 0) ZG_HIP(ctx, hipMemcpyAsync(buf + pa, q, qb, hipMemcpyHostToDevice, ctx->stream));
+  if (op != 0 && op < 4) ZG_HIP(ctx, hipMemcpyAsync(buf + pa, q, qb, hipMemcpyHostToDevice, ctx->stream));
   ZG_TRY(msm_build_table<F>(ctx, (Affine<F>*)buf, n, 0));
   if (op == 1 || op == 2) ZG_TRY(msm_build_table<F>(ctx, (Affine<F>*)(buf + pa), n, 0));
   const unsigned lanes = (unsigned)n * MsmOps<F>::LP;
-  k_group_op_msm<F><<<(lanes + 63) / 64, 64, 0, ctx->stream>>>(op, (const Affine<F>*)buf, buf + pa,
-                                                             (XYZZ<F>*)(buf + pa + qa), (uint32_t)n);
+  if constexpr (sizeof(F) > sizeof(Fq)) {
+    if (op >= 4) {
+      // the psi constants, as one packed "point"
+      Affine<Fq2> k = {g2_subgroup_consts().psi_x, g2_subgroup_consts().psi_y};
+      k = MsmOps<Fq2>::to_internal(k);
+      ZG_HIP(ctx, hipMemcpyAsync(buf + pa, &k, sizeof k, hipMemcpyHostToDevice, ctx->stream));
+      ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (k is a local)
+      k_g2_endo_msm<<<(lanes + 63) / 64, 64, 0, ctx->stream>>>(op, (const Affine<Fq2>*)buf, (const Affine<Fq2>*)(buf + pa),
+                                                              (XYZZ<Fq2>*)(buf + pa + qa), (uint32_t)n);
+    }
+  }
+  if (op < 4)
+    k_group_op_msm<F><<<(lanes + 63) / 64, 64, 0, ctx->stream>>>(op, (const Affine<F>*)buf, buf + pa,
+                                                               (XYZZ<F>*)(buf + pa + qa), (uint32_t)n);
   ZG_HIP(ctx, hipGetLastError());
   std::vector<XYZZ<F>> host(n);
   ZG_HIP(ctx, hipMemcpyAsync(host.data(), buf + pa + qa, ob, hipMemcpyDeviceToHost, ctx->stream));
@@ -157,11 +216,14 @@ zg16_status zg16_selftest_field(zg16_ctx* ctx, int field, int op, const uint64_t
 
 zg16_status zg16_selftest_group(zg16_ctx* ctx, int group, int op, const uint64_t* p, const uint64_t* q, size_t n,
                                 uint64_t* out) {
-  if (!ctx || !p || !out || !n || op < 0 || op > 3 || (op && !q) || n > (1u << 24)) return zg::fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "bad selftest arguments");
+  const bool endo = group == 4 && (op >= 4 && op <= 6);  // the G2 subgroup test: its two sides, its kernel
+  if (!ctx || !p || !out || !n || op < 0 || (op > 3 && !endo) || (op && !endo && !q) || n > (1u << 24))
+    return zg::fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "bad selftest arguments");
   ZG_HIP(ctx, hipSetDevice(ctx->device));
   if (group == 1) return zg::run_group<zg::Fq>(ctx, op, p, q, n, out);
   if (group == 2) return zg::run_group<zg::Fq2>(ctx, op, p, q, n, out);
   if (group == 3) return zg::run_group_msm<zg::Fq>(ctx, op, p, q, n, out);
+  if (group == 4 && op == 6) return zg::run_g2_subgroup_kernel(ctx, p, n, out);
   if (group == 4) return zg::run_group_msm<zg::Fq2>(ctx, op, p, q, n, out);
   return zg::fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "unknown group %d", group);
 }

@@ -15,6 +15,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <thread>
 #include <vector>
 
 #include "field.hpp"
@@ -253,6 +254,45 @@ void zgt_setup_scalars(const zgt_circuit* c, const uint64_t* lag, const uint64_t
       memcpy(l_s + 4 * (v - n_in), &t, 32);
     }
   }
+}
+
+// Affine points (Montgomery limbs; all-zero = the identity) -> pairing_ce's uncompressed encoding, the form the
+// vectors of a `Parameters::write` key file hold: 32-byte big-endian canonical coordinates, G1 = x || y,
+// G2 = x.c1 || x.c0 || y.c1 || y.c0, the identity as 0x40 followed by zeros.  coords: Fq values per point (2 for
+// G1, 4 for G2).  Split over `threads` host threads.  Benchmarks use it to make key files of 2^20 .. 2^24-row
+// circuits (zinc-vm writes such a file at zinc-vm/src/zvm/arguments/command/setup.rs:67-69).
+void zgt_points_encode(const uint64_t* pts, uint64_t n, int coords, uint8_t* out, int threads) {
+  auto work = [=](uint64_t lo, uint64_t hi) {
+    static const int order_g1[2] = {0, 1}, order_g2[4] = {1, 0, 3, 2};
+    const int* order = coords == 2 ? order_g1 : order_g2;
+    for (uint64_t i = lo; i < hi; i++) {
+      const uint64_t* p = pts + i * 4 * coords;
+      uint8_t* o = out + i * 32 * coords;
+      uint64_t any = 0;
+      for (int k = 0; k < 4 * coords; k++) any |= p[k];
+      if (!any) {
+        memset(o, 0, 32 * coords);
+        o[0] = 0x40;
+        continue;
+      }
+      for (int c = 0; c < coords; c++) {
+        Fq m;
+        memcpy(&m, p + 4 * order[c], 32);
+        const Fq x = from_mont(m);
+        for (int l = 0; l < 8; l++) {
+          uint8_t* b = o + 32 * c + 28 - 4 * l;
+          b[0] = (uint8_t)(x.v[l] >> 24); b[1] = (uint8_t)(x.v[l] >> 16); b[2] = (uint8_t)(x.v[l] >> 8); b[3] = (uint8_t)x.v[l];
+        }
+      }
+    }
+  };
+  if (threads < 2 || n < 4096) {
+    work(0, n);
+    return;
+  }
+  std::vector<std::thread> pool;
+  for (int t = 0; t < threads; t++) pool.emplace_back(work, n * t / threads, n * (t + 1) / threads);
+  for (auto& th : pool) th.join();
 }
 
 // Small Fr helpers for Python callers (Montgomery limbs in and out)

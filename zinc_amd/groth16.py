@@ -265,10 +265,16 @@ class DeviceKey:
 
     @classmethod
     def from_bytes(cls, ctx, data, checked=True, shard_index=0, shard_count=1):
-        """bellman `Parameters::read(reader, checked)` on the GPU: `data` is the proving-key file."""
+        """bellman `Parameters::read(reader, checked)` on the GPU: `data` is the proving-key file (bytes, or a
+        uint8 numpy array -- e.g. an np.memmap of the file -- which is handed over without a copy)."""
         key = cls(ctx, None)
-        data = bytes(data)
-        _check(ctx.handle, ctx._lib.zg16_pk_upload_bytes(ctx.handle, data, len(data), int(checked), shard_index,
+        if isinstance(data, np.ndarray):
+            arr = np.ascontiguousarray(data, dtype=np.uint8)
+            ptr, size = C.cast(C.c_void_p(arr.ctypes.data), C.c_char_p), arr.size
+        else:
+            arr = bytes(data)
+            ptr, size = arr, len(arr)
+        _check(ctx.handle, ctx._lib.zg16_pk_upload_bytes(ctx.handle, ptr, size, int(checked), shard_index,
                                                          shard_count, C.byref(key.handle)))
         return key
 

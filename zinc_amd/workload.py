@@ -42,6 +42,7 @@ def tools():
         t.zgt_circuit_satisfied.restype = C.c_int
         t.zgt_circuit_satisfied.argtypes = [C.c_void_p]
         t.zgt_powers.argtypes = [u64p, u64p, C.c_uint64, u64p]
+        t.zgt_points_encode.argtypes = [u64p, C.c_uint64, C.c_int, C.c_void_p, C.c_int]
         t.zgt_setup_scalars.argtypes = [C.c_void_p, u64p, u64p, u64p, u64p, u64p, u64p, u64p, u64p, u64p]
         _tools = t
     return _tools
@@ -214,3 +215,31 @@ def generate_parameters_host(ctx, circuit, toxic):
     params.gamma_g2 = fixed_base_g2(ctx, g2, mont(gamma))
     params.ic = ic
     return params
+
+
+def params_file_bytes(params, threads=None):
+    """The bytes bellman's `Parameters::write` produces for `params` (zinc-vm writes them at
+    zinc-vm/src/zvm/arguments/command/setup.rs:67-69 and `zvm prove` reads them back at prove.rs:73-76), as a
+    uint8 array: verifying key, then h, l, a, b_g1 (G1) and b_g2 (G2), each a big-endian u32 count and uncompressed
+    points.  The point encoding runs in libzg16_tools on the host's threads, so that key files of 2^20 .. 2^24-row
+    circuits (0.4 .. 6 GB) are made in seconds; zinc_amd.codec.params_write is the same format point by point."""
+    t = tools()
+    threads = threads or min(16, os.cpu_count() or 1)
+    f = lambda x, w: np.ascontiguousarray(x, dtype=np.uint64).reshape(-1, w)
+    parts = [(f(params.alpha_g1, 8), 2, False), (f(params.beta_g1, 8), 2, False), (f(params.beta_g2, 16), 4, False),
+             (f(params.gamma_g2, 16), 4, False), (f(params.delta_g1, 8), 2, False), (f(params.delta_g2, 16), 4, False),
+             (f(params.ic, 8), 2, True), (f(params.h, 8), 2, True), (f(params.l, 8), 2, True), (f(params.a, 8), 2, True),
+             (f(params.b_g1, 8), 2, True), (f(params.b_g2, 16), 4, True)]
+    total = sum(arr.shape[0] * 32 * coords + (4 if counted else 0) for arr, coords, counted in parts)
+    out = np.zeros(total, dtype=np.uint8)
+    pos = 0
+    for arr, coords, counted in parts:
+        n = arr.shape[0]
+        if counted:
+            out[pos:pos + 4] = np.frombuffer(int(n).to_bytes(4, "big"), dtype=np.uint8)
+            pos += 4
+        if n:
+            t.zgt_points_encode(_lib.as_u64p(arr), n, coords, C.c_void_p(out.ctypes.data + pos), threads)
+        pos += n * 32 * coords
+    assert pos == total
+    return out
