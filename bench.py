@@ -468,14 +468,13 @@ def secondary_block(ctx, d, args, split_for):
                 "seconds": sec, "points_per_s": n / sec, "bases_s_untimed": t1 - t0, "upload_and_tables_s_untimed": t2 - t1,
                 "roofline": accumulate_roofline(stats)}
 
-    def small_circuit():
-        """The small-circuit latency floor: the hand-recorded factorial.zn stand-in (zinc_amd/standin.py; about
-        1.8 k rows, domain 2^11 -- the size of a real zinc-tester program or contract method), key generated on the
-        GPU, proof checked by the library's verifier against the output the reference's test pins."""
+    def small_circuit(circ, label):
+        """The small-circuit latency floor: a hand-recorded stand-in (zinc_amd/standin.py; a few thousand rows -- the
+        size of a real zinc-tester program or contract method), key generated on the GPU, proof checked by the
+        library's verifier against the public inputs."""
         from zinc_amd import standin
         from zinc_amd.groth16 import prove_recorded, verify_proof
         from zinc_amd.fields import ints_to_mont, R_MOD
-        circ = standin.FactorialCircuit(6)
         pa = standin.record(circ)
         r1cs = pa.r1cs()
         t0 = time.perf_counter()
@@ -496,16 +495,23 @@ def secondary_block(ctx, d, args, split_for):
         finally:
             key.free()
             mat.free()
-        return {"workload": "hand-recorded stand-in for zinc-tester/tests/algorithm/factorial.zn (n = 6 -> 720), %d rows, "
-                            "witness from host memory" % r1cs.n_rows,
-                "ms_per_proof": 1e3 * sec, "proofs_timed": 50, "verifies_against_pinned_output": bool(ok),
+        return {"workload": "%s, %d rows, witness from host memory" % (label, r1cs.n_rows),
+                "ms_per_proof": 1e3 * sec, "proofs_timed": 50, "verifies_against_public_inputs": bool(ok),
+                "public_inputs": [str(v) for v in circ.public_inputs()],
                 "verify_ms_host": 1e3 * verify_s, "keygen_s": keygen_s, "key_upload_and_tables_s": key_upload_s}
 
     guarded("prove_2p%d" % args.secondary_log_rows,
             lambda: prove_case(args.secondary_log_rows, False, 3, "prove_2p%d_host_witness" % args.secondary_log_rows,
                                "cold_start_keyfile_2p%d" % args.secondary_log_rows))
     if d.world == 1:
-        guarded("small_circuit_factorial", small_circuit)
+        from zinc_amd import standin
+        guarded("small_circuit_factorial", lambda: small_circuit(
+            standin.FactorialCircuit(6), "hand-recorded stand-in for zinc-tester/tests/algorithm/factorial.zn (n = 6 -> 720, the "
+                                         "output the reference's test pins)"))
+        guarded("small_circuit_uniswap", lambda: small_circuit(
+            standin.UniswapInputPriceCircuit(10 ** 18, 5 * 10 ** 21, 7 * 10 ** 23, 0xC0FFEE << 200),
+            "hand-recorded stand-in for get_eth_to_token_input_price of zinc-examples/uniswap/src/main.zn:705-712 (a contract "
+            "method: price and storage root are the public inputs; the reference pins no output for it)"))
     guarded("prove_2p%d_dense" % min(args.log_rows, 20),
             lambda: prove_case(min(args.log_rows, 20), True, 10, None, "cold_start_keyfile_2p%d" % min(args.log_rows, 20)))
     # the metric's second half: G1 multiexp points per second at the two headline sizes, then the stand-alone size

@@ -1054,3 +1054,54 @@ def test_factorial_stand_in_proves_and_verifies(gpu_ctx, n, storage_root):
     # the library's own verifier agrees with the oracle's
     from zinc_amd.groth16 import verify_proof
     assert verify_proof(params, got, public) and not verify_proof(params, got, [public[0] + 1] + public[1:])
+
+
+
+def _stand_in_programs():
+    from zinc_amd import standin
+    return [("fibonacci.zn/12", lambda: standin.FibonacciCircuit(12), [89]),
+            ("fibonacci.zn/16", lambda: standin.FibonacciCircuit(16), [610]),
+            ("division_u8.zn/48/7", lambda: standin.DivisionU8Circuit(48, 7), [6]),
+            ("division_u8.zn/255/255", lambda: standin.DivisionU8Circuit(255, 255), [1]),
+            ("uniswap/get_eth_to_token_input_price",
+             lambda: standin.UniswapInputPriceCircuit(10 ** 18, 5 * 10 ** 21, 7 * 10 ** 23, 0xC0FFEE << 200), None)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", range(5))
+def test_more_stand_ins_prove_and_verify(gpu_ctx, which):
+    """More hand-recorded programs: zinc-tester's fibonacci.zn and division_u8.zn (each verifies against the output
+    its `//!` header pins: proof_check.rs:243-264 is `verify == true`) and the uniswap example's
+    get_eth_to_token_input_price (zinc-examples/uniswap/src/main.zn:705-712 -- a contract method: its storage root
+    is the last public input; the reference holds no expected output for it, the public input is the formula's
+    value).  Proof bit-identical to the CPU restatement; both verifiers accept it and refuse a changed input."""
+    from oracle import cpu_binding as cb
+    from oracle import groth16 as G
+    from zinc_amd import standin, workload
+    from zinc_amd.groth16 import verify_proof
+    name, make, pinned = _stand_in_programs()[which]
+    circ = make()
+    pa = standin.record(circ)
+    public = circ.public_inputs()
+    if pinned is not None:
+        assert public == pinned
+    else:
+        assert public == [standin.UniswapInputPriceCircuit.price(10 ** 18, 5 * 10 ** 21, 7 * 10 ** 23), (0xC0FFEE << 200) % R_MOD]
+    r1cs = pa.r1cs()
+    params = workload.generate_parameters(gpu_ctx, r1cs, dict(k1=3, k2=5, alpha=7, beta=11, gamma=13, delta=17, tau=0xFAC71 + which))
+    zi, za = pa.witness()
+    rs = ints_to_mont([0x5EED + which, 0xFEED], R_MOD)
+    st, want, _ = cb.prove(params, r1cs, zi, za, rs[0], rs[1], threads=4)
+    assert st == 0
+    key, mat = params.upload(gpu_ctx), r1cs.upload(gpu_ctx)
+    got = prove_recorded(gpu_ctx, key, mat, zi, za, rs[0], rs[1])
+    key.free()
+    mat.free()
+    for g, w in zip((got.raw.a, got.raw.b, got.raw.c), want):
+        assert np.array_equal(np.frombuffer(bytes(g), dtype=np.uint64), w), name
+    assert G.verify_proof(_vk_of(params), got.as_tuple(), public)
+    assert verify_proof(params, got, public)
+    for k in range(len(public)):
+        bad = list(public)
+        bad[k] = (bad[k] + 1) % R_MOD
+        assert not verify_proof(params, got, bad)

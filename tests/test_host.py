@@ -418,3 +418,49 @@ def test_key_file_encoder_matches_codec():
     p = Parameters.from_points(k)
     p.gamma_g2, p.ic = g2_to_mont([k.gamma_g2]), g1_to_mont(k.ic)
     assert bytes(workload.params_file_bytes(p)) == codec.params_write(k)
+
+
+
+@pytest.mark.parametrize("name", ["fibonacci", "division", "uniswap", "factorial_contract"])
+def test_more_stand_in_rows(name):
+    """The other hand-recorded programs (zinc-tester's fibonacci.zn and division_u8.zn, the uniswap example's
+    get_eth_to_token_input_price, factorial.zn wrapped as a contract method): the outputs are the reference's pinned
+    ones, every row is satisfied and canonical (constraint_systems/dedup.rs:30-69), every aux variable occurs in a
+    row, and the matrices do not depend on the inputs."""
+    from zinc_amd import standin
+    from zinc_amd.fields import R_MOD
+    S = standin
+    cases = {
+        "fibonacci": [(S.FibonacciCircuit(n), [w]) for n, w in S.FibonacciCircuit.CASES.items()],
+        "division": [(S.DivisionU8Circuit(a, b), [w]) for (a, b), w in S.DivisionU8Circuit.CASES.items()],
+        "uniswap": [(S.UniswapInputPriceCircuit(e, b, t, 77), [S.UniswapInputPriceCircuit.price(e, b, t), 77])
+                    for e, b, t in ((10 ** 18, 5 * 10 ** 21, 7 * 10 ** 23), (1, 1, 1), (3 * 10 ** 30, 10 ** 9, 10 ** 40))],
+        "factorial_contract": [(S.FactorialCircuit(6, storage_root=5), [720, 5])],
+    }[name]
+    shapes = set()
+    for circ, want in cases:
+        pa = S.record(circ)
+        assert circ.public_inputs() == want and pa.z_in == [1] + want
+        z = lambda v: pa.z_aux[v & 0x7fffffff] if v & (1 << 31) else pa.z_in[v]
+        n_rows = len(pa._rp[0]) - 1
+        for r in range(n_rows):
+            vals = []
+            for k in range(3):
+                lo, hi = pa._rp[k][r], pa._rp[k][r + 1]
+                cols = pa._col[k][lo:hi]
+                key = [((c >> 31), c & 0x7fffffff) for c in cols]
+                assert key == sorted(set(key)), "row %d matrix %d is not canonical" % (r, k)
+                assert all(pa._coeff[k][lo:hi])
+                vals.append(sum(co * z(c) for c, co in zip(cols, pa._coeff[k][lo:hi])) % R_MOD)
+            assert vals[0] * vals[1] % R_MOD == vals[2], "row %d is not satisfied" % r
+        seen = {c for k in range(3) for c in pa._col[k] if c & (1 << 31)}
+        assert len(seen) == len(pa.z_aux)
+        shapes.add((tuple(map(tuple, pa._rp)), tuple(map(tuple, pa._col)), tuple(map(tuple, pa._coeff))))
+    assert len(shapes) == 1, "the matrices depend on the inputs"
+    # division by zero and a failed require are refused at synthesis, as the reference's VM refuses them
+    if name == "division":
+        with pytest.raises(AssertionError):
+            S.record(S.DivisionU8Circuit(42, 0))
+    if name == "uniswap":
+        with pytest.raises(AssertionError):
+            S.record(S.UniswapInputPriceCircuit(0, 1, 1, 77))
