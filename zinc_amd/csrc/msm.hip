@@ -1524,8 +1524,13 @@ extern "C" zg16_status zg16_msm_resident_noalloc(zg16_ctx* ctx, const zg16_bases
   if (!ws) return fail(ctx, ZG16_ERR_DEVICE, "no static workspace on GPU %d", ctx->device);
   const Fr* d_s = (const Fr*)scalars;
   if (!on_device && b->n) {
+    // through the context's page-locked block (its third megabyte; the result block below uses the first): a copy
+    // from pageable memory is staged by the runtime in buffers of its own, which it may allocate on the way
+    static_assert(NOALLOC_MAX_POINTS * sizeof(Fr) <= MSM_PINNED_BYTES, "the staged scalars fit one pinned block");
+    void* host_stage = (char*)ctx->pinned + 2 * MSM_PINNED_BYTES;
+    memcpy(host_stage, scalars, b->n * sizeof(Fr));
     Fr* staged = (Fr*)(ws + NOALLOC_MSM_BYTES);
-    ZG_HIP(ctx, hipMemcpyAsync(staged, scalars, b->n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    ZG_HIP(ctx, hipMemcpyAsync(staged, host_stage, b->n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
     d_s = staged;
   }
   const MsmWorkspace fixed = {(char*)ws, NOALLOC_MSM_BYTES};
