@@ -439,7 +439,8 @@ zg16_status zg16_last_timings(const zg16_ctx* ctx, zg16_timings* out);
  * op: 0 double p, 1 p + q (mixed), 2 p + q (projective), 3 k * p with k a Montgomery Fr; group 4 only (q unused):
  * 4 [6 x^2] p and 5 psi(p), the two sides of the subgroup test the key-file decoder runs on every b_g2 point
  * (x the BN parameter, psi the untwist-Frobenius-twist map); 6 the decoder's own kernel on each point: the first
- * limb of out[i] is 1 when it accepts p[i], else 0.
+ * limb of out[i] is 1 when it accepts p[i], else 0.  Groups 3 and 4: 7 p + q and 8 2p + 2q through the addition the
+ * sums that end a multiexp use (a G1 point spread over four lanes, one coordinate each; 8 chains three of them).
  * Inputs and outputs are affine points / Montgomery limbs in host memory. */
 zg16_status zg16_selftest_field(zg16_ctx* ctx, int field, int op, const uint64_t* a, const uint64_t* b,
                                 size_t n, uint64_t* out);

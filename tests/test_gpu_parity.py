@@ -76,12 +76,18 @@ def test_group_ops_golden(gpu_ctx, name, group):
     Q = [unhex(c["q"]) for c in fx["cases"]]
     neg = lambda p: (p[0], (-p[1]) % Q_MOD) if group in (1, 3) else (p[0], ((-p[1][0]) % Q_MOD, (-p[1][1]) % Q_MOD))
     assert run(0, to_m(P), to_m(P)) == [unhex(c["dbl"]) for c in fx["cases"]]
-    for op in (1, 2):  # mixed and projective addition, including every exceptional case
+    # mixed and projective addition, including every exceptional case; 7: the addition spread over lanes that
+    # the closing sums of a multiexp use
+    for op in (1, 2) + ((7,) if group in (3, 4) else ()):
         assert run(op, to_m(P), to_m(Q)) == [unhex(c["add"]) for c in fx["cases"]]
         assert run(op, to_m(P), to_m(P)) == [unhex(c["add_self"]) for c in fx["cases"]]
         assert run(op, to_m(P), to_m([neg(p) for p in P])) == [None] * len(P)
         assert run(op, to_m(P), to_m([None] * len(P))) == P
         assert run(op, to_m([None] * len(P)), to_m(Q)) == Q
+    if group in (3, 4):  # op 8: 2p + 2q through three chained additions of the spread form
+        twice = lambda pts: run(0, to_m(pts), to_m(pts))
+        for q in (Q, P, [neg(p) for p in P]):
+            assert run(8, to_m(P), to_m(q)) == run(2, to_m(twice(P)), to_m(twice(q)))
     sm = fx["scalar_mul"]
     ks = ints_to_mont([int(c["k"], 16) for c in sm["cases"]], R_MOD)
     pts = to_m([unhex(sm["p"])] * len(sm["cases"]))

@@ -123,6 +123,93 @@ ZG_D void add_full29(XYZZ29<P>& acc, const XYZZ29<P>& p) {
   acc.zzz = mul(mul(acc.zzz, p.zzz), ppp);
 }
 
+// ---- G1 over a lane quad ----------------------------------------------------------------------
+// The sums that END a multiexp (bucket folds, workgroup trees) are chains of dependent additions with few points
+// in flight: a wave that holds one point per lane spends the 14 products of an addition one after another
+// (about 7 us) however few of its lanes carry a live point.  Spread over four lanes -- lane q of a quad holds
+// coordinate q of (X, Y, ZZ, ZZZ), nine registers instead of 36 -- the products of add-2008-s run four at a time:
+//   round 1   u1 = X1 ZZ2 | s1 = Y1 ZZZ2 | u2 = X2 ZZ1 | s2 = Y2 ZZZ1      (each lane: own coordinate of one
+//             operand times the coordinate two lanes over of the other)
+//   round 2   pp = (u2-u1)^2 | rr = (s2-s1)^2 | ZZ1 ZZ2 | ZZZ1 ZZZ2
+//   round 3   q = u1 pp | ppp = (u2-u1) pp | ZZ3 = ZZ1 ZZ2 pp | ppp again
+//   round 4   X3 = rr - ppp - 2q (no product) | Y3 = r (q - X3) - s1 ppp (one fused scan) | - | ZZZ3 = ZZZ1 ZZZ2 ppp
+// 4.5 product times instead of 13.5, plus 54 DPP moves.  Same bounds as add_full29.
+template <int CTRL>
+ZG_D uint32_t quad_perm(uint32_t x) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, true);
+}
+template <int CTRL, class P>
+ZG_D Fp29<P> quad_perm(const Fp29<P>& a) {
+  Fp29<P> r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.v[i] = quad_perm<CTRL>(a.v[i]);
+  return r;
+}
+static constexpr int QUAD_X2 = 0x4E;  // quad_perm [2,3,0,1]: the lane two over
+static constexpr int QUAD_X1 = 0xB1;  // quad_perm [1,0,3,2]
+static constexpr int QUAD_B0 = 0x00, QUAD_B1 = 0x55, QUAD_B2 = 0xAA, QUAD_B3 = 0xFF;  // lane k of the quad, in all four
+
+template <class P>
+ZG_D Fp29<P> pick(bool c, const Fp29<P>& a, const Fp29<P>& b) {
+  Fp29<P> r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.v[i] = c ? a.v[i] : b.v[i];
+  return r;
+}
+
+// this lane's coordinate of a point that every lane of the quad holds whole
+template <class P>
+ZG_D Fp29<P> quad_own(const XYZZ29<P>& p) {
+  const uint32_t c = threadIdx.x & 3;
+  return pick(c < 2, pick(c == 0, p.x, p.y), pick(c == 2, p.zz, p.zzz));
+}
+// the whole point of a quad, in each of its lanes
+template <class P>
+ZG_D XYZZ29<P> quad_whole(const Fp29<P>& own) {
+  return {quad_perm<QUAD_B0>(own), quad_perm<QUAD_B1>(own), quad_perm<QUAD_B2>(own), quad_perm<QUAD_B3>(own)};
+}
+template <class P>
+ZG_D bool quad_is_inf(const Fp29<P>& own) {
+  return quad_perm<QUAD_B2>((uint32_t)own.is_zero_limbs()) != 0;
+}
+
+// a += b, both spread over the quad.  No branch on the common paths (identity operands are selected at the end), so
+// every lane of a wave walks the same instructions whatever its quad holds.
+template <class P>
+ZG_D void quad_add(Fp29<P>& a, const Fp29<P>& b) {
+  using F = Fp29<P>;
+  const uint32_t c = threadIdx.x & 3;
+  const bool hi = c >= 2;
+  const bool ainf = quad_is_inf(a), binf = quad_is_inf(b);
+  const F bx = quad_perm<QUAD_X2>(b);
+  const F m1 = mul(a, bx);                          // u1 | s1 | u2 | s2 : 8*2, 5*2 -> <2
+  const F mx = quad_perm<QUAD_X2>(m1);
+  const F d = sub_k(pick(hi, m1, mx), pick(hi, mx, m1), P::K3);  // u2 - u1 | s2 - s1 | u2 - u1 | s2 - s1 : <5
+  const F m2 = mul(pick(hi, a, d), pick(hi, b, d));  // pp | rr | ZZ1 ZZ2 | ZZZ1 ZZZ2 : 25, 4 -> <2
+  if (quad_perm<QUAD_B0>((uint32_t)is_zero_mod_p(m2)) != 0 && !ainf && !binf) {
+    // same x: doubling or cancellation (rare) -- every lane takes the whole points and the one-lane formulas
+    XYZZ29<P> wa = quad_whole(a);
+    add_full29(wa, quad_whole(b));
+    a = quad_own(wa);
+    return;
+  }
+  const F pp0 = quad_perm<QUAD_B0>(m2), d0 = quad_perm<QUAD_B0>(d);
+  const F m3 = mul(pick(c == 0, m1, pick(c == 2, m2, d0)), pp0);  // q | ppp | ZZ3 | ppp : 2*2, 5*2 -> <2
+  const F m2s = quad_perm<QUAD_X1>(m2), m3s = quad_perm<QUAD_X1>(m3);
+  const bool l0 = c == 0;                           // lanes 0 and 1 both form X3 (lane 0 keeps it, lane 1 needs it)
+  const F q = pick(l0, m3, m3s), ppp = pick(l0, m3s, m3);
+  const F x3 = sub2_k(pick(l0, m2s, m2), ppp, q, P::K6);  // rr - ppp - 2q : <8
+  const F t = sub_k(q, x3, P::K8);                  // <10
+  const bool l3 = c == 3;
+  // lane 1: r t - s1 ppp (50 + 2*2); lane 3: ZZZ1 ZZZ2 ppp through the same scan with nothing subtracted.
+  // (Measured and dropped: s1 ppp on the idle lane 0 and a plain product in every lane -- half a product time less.
+  // It is exact (checked limb by limb on the host, and alone on the GPU), but k_sum_range built with it by hipcc 7.2
+  // returned wrong sums, so the fused scan stays.)
+  const F m4 = mul_sub(pick(l3, m2, d), pick(l3, m3, t), m1, pick(l3, F::zero(), m3), P::KS2);
+  const F sum = pick(l0, x3, pick(c == 2, m3, m4));
+  a = pick(binf, a, pick(ainf, b, sum));
+}
+
 // ---- G2 over a lane pair -----------------------------------------------------------------------
 // The same formulas over Fq2 with every value split across lanes 2k (real) and 2k+1 (imaginary), see
 // mul_pair.  XYZZ29 / Affine29 then hold ONE lane's components.  Bounds in units of p, per component:
@@ -231,6 +318,88 @@ ZG_D void add_full_pair(XYZZ29<P>& acc, const XYZZ29<P>& p) {
   acc.y = y3;
   acc.zz = mul_pair(mul_pair(acc.zz, p.zz, P::KS2), pp, P::KS2);
   acc.zzz = mul_pair(mul_pair(acc.zzz, p.zzz, P::KS2), ppp, P::KS2);
+}
+
+// ---- G2 over a lane octet ---------------------------------------------------------------------
+// quad_add's schedule with every Fq2 coordinate on a lane pair: lane 2 pos + comp of an octet holds component comp
+// (0 real, 1 imaginary) of the coordinate at position pos, positions being X, Y, ZZZ, ZZ -- so that the coordinate an
+// addition's first products pair up (X with ZZ, Y with ZZZ) sits at position 3 - pos, which together with the other
+// component is the mirror image inside the octet (one DPP move).  Four mul_pair times instead of fourteen.
+//   stored points:  X < 6,  Y < 4,  ZZ, ZZZ < 2  per component, as for the lane-pair form
+ZG_D uint32_t oct_mirror(uint32_t x) {  // lane 7 - l of the octet: position 3 - pos, the OTHER component
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x141 /* row_half_mirror */, 0xf, 0xf, true);
+}
+template <int POS>
+ZG_D uint32_t oct_from(uint32_t x) {  // position POS of the octet, same component
+  return (uint32_t)__builtin_amdgcn_ds_swizzle((int)x, 0x0019 | (POS << 6));  // lane = (lane & 0b11001) | POS << 1
+}
+template <class P>
+ZG_D Fp29<P> oct_mirror(const Fp29<P>& a) {
+  Fp29<P> r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.v[i] = oct_mirror(a.v[i]);
+  return r;
+}
+template <int POS, class P>
+ZG_D Fp29<P> oct_from(const Fp29<P>& a) {
+  Fp29<P> r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.v[i] = oct_from<POS>(a.v[i]);
+  return r;
+}
+ZG_D uint32_t oct_pos() { return (threadIdx.x >> 1) & 3; }
+// which of x, y, zz, zzz a position holds
+ZG_D uint32_t oct_coord(uint32_t pos) { return pos < 2 ? pos : 5 - pos; }
+
+// this lane's part of a point that every lane pair of the octet holds whole (in the lane-pair form)
+template <class P>
+ZG_D Fp29<P> oct_own(const XYZZ29<P>& p) {
+  const uint32_t pos = oct_pos();
+  return pick(pos < 2, pick(pos == 0, p.x, p.y), pick(pos == 2, p.zzz, p.zz));
+}
+// the whole point of an octet in the lane-pair form, in each of its pairs
+template <class P>
+ZG_D XYZZ29<P> oct_whole(const Fp29<P>& own) {
+  return {oct_from<0>(own), oct_from<1>(own), oct_from<3>(own), oct_from<2>(own)};
+}
+template <class P>
+ZG_D bool oct_is_inf(const Fp29<P>& own) {
+  return pair_both(oct_from<3>((uint32_t)own.is_zero_limbs()) != 0);
+}
+
+// a += b, both spread over the octet; no branch on the common paths (see quad_add)
+template <class P>
+ZG_D void oct_add(Fp29<P>& a, const Fp29<P>& b) {
+  using F = Fp29<P>;
+  const uint32_t pos = oct_pos();
+  const bool lo = pos < 2;
+  const bool ainf = oct_is_inf(a), binf = oct_is_inf(b);
+  const F bxo = oct_mirror(b), bx = pair_swap(bxo);  // b's coordinate at 3 - pos: the partner's component, this lane's
+  // u1 = X1 ZZ2 | s1 = Y1 ZZZ2 | s2 = ZZZ1 Y2 | u2 = ZZ1 X2 : 6 * (6 + 8) -> < 2 (the widest pairing bounds them all)
+  const F m1 = mul_pair_x(a, pair_swap(a), bx, bxo, P::KS8);
+  const F mx = pair_swap(oct_mirror(m1));
+  const F d = sub_k(pick(lo, mx, m1), pick(lo, m1, mx), P::K2);  // u2 - u1 | s2 - s1 | s2 - s1 | u2 - u1 : < 3.2
+  const F m2 = mul_pair(pick(lo, d, a), pick(lo, d, b), P::KS4);  // pp | rr | ZZZ1 ZZZ2 | ZZ1 ZZ2 : 3.2 * 7.2
+  if (pair_both(oct_from<0>((uint32_t)is_zero_mod_p(m2)) != 0) && !ainf && !binf) {
+    // same x: doubling or cancellation (rare) -- every pair takes the whole points and the lane-pair formulas
+    XYZZ29<P> wa = oct_whole(a);
+    add_full_pair(wa, oct_whole(b));
+    a = oct_own(wa);
+    return;
+  }
+  const F pp0 = oct_from<0>(m2), d0 = oct_from<0>(d);
+  // q = u1 pp | ppp | ppp | ZZ3 = ZZ1 ZZ2 pp : 3.2 * (2 + 2)
+  const F m3 = mul_pair(pick(pos == 0, m1, pick(pos == 3, m2, d0)), pp0, P::KS2);
+  const F m1s = quad_perm<QUAD_X2>(m1), m2s = quad_perm<QUAD_X2>(m2), m3s = quad_perm<QUAD_X2>(m3);  // positions 0 <-> 1
+  const bool p0 = pos == 0;
+  const F q = pick(p0, m3, m3s), ppp = pick(p0, m3s, m3);
+  const F x3 = sub2_k(pick(p0, m2s, m2), ppp, q, P::K4);  // rr - ppp - 2q : < 5.2
+  const F t = sub_k(q, x3, P::K6);                        // < 7.2
+  // s1 ppp | t r | ZZZ1 ZZZ2 ppp | - : 7.2 * (3.2 + 4)
+  const F m4 = mul_pair(pick(p0, m1s, pick(pos == 1, t, m2)), pick(p0, m3s, pick(pos == 1, d, m3)), P::KS4);
+  const F y3 = sub_k(m4, quad_perm<QUAD_X2>(m4), P::K2);  // position 1: t r - s1 ppp : < 3.4
+  const F sum = pick(p0, x3, pick(pos == 1, y3, pick(pos == 2, m4, m3)));
+  a = pick(binf, a, pick(ainf, b, sum));
 }
 
 // ---- the two sides of the G2 subgroup test psi(P) = [6x^2] P (see g2_in_subgroup in curve.hpp), on a lane pair ----

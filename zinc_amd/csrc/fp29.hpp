@@ -224,10 +224,10 @@ ZG_D bool pair_both(bool x) { return x && pair_swap((uint32_t)x) != 0; }
 // This lane's component of a*b.  b's components must have normalised limbs and lie below the multiple
 // KS of p (one of P::KS*) with a margin; the result is below 2p when
 // (bound of a) * (bound of b + KS / p) <= 169, and has normalised limbs.
+// (ao, bo: the pair partner's components of a and b, for callers that hold them already.)
 template <class P>
-ZG_D Fp29<P> mul_pair(const Fp29<P>& a, const Fp29<P>& b, const uint32_t (&KS)[9]) {
+ZG_D Fp29<P> mul_pair_x(const Fp29<P>& a, const Fp29<P>& ao, const Fp29<P>& b, const Fp29<P>& bo, const uint32_t (&KS)[9]) {
   const bool im = (threadIdx.x & 1) != 0;
-  const Fp29<P> ao = pair_swap(a), bo = pair_swap(b);
   uint32_t v[9], z[9];
 #pragma unroll
   for (int i = 0; i < 9; i++) {
@@ -261,6 +261,10 @@ ZG_D Fp29<P> mul_pair(const Fp29<P>& a, const Fp29<P>& b, const uint32_t (&KS)[9
   }
   r.v[8] = (uint32_t)acc;
   return r;
+}
+template <class P>
+ZG_D Fp29<P> mul_pair(const Fp29<P>& a, const Fp29<P>& b, const uint32_t (&KS)[9]) {
+  return mul_pair_x(a, pair_swap(a), b, pair_swap(b), KS);
 }
 
 // Is the product-normalised value a (below 2p, limbs strictly below 2^29) zero modulo p?

@@ -565,54 +565,110 @@ ZG_D typename MsmOps<F>::Pt mul_small(const typename MsmOps<F>::Pt& p, uint32_t 
   return acc;
 }
 
-// Workgroup tree sum through LDS (256 lanes = 256 / LP logical threads); the result is valid in
-// logical thread 0.  sh holds 128 lanes' worth of points.
+// ---- sums in the spread form (see quad_add) ----------------------------------------------------------------------
+// What a workgroup sum needs in LDS: a parking slot per logical thread and the four waves' sums.
 template <class F>
-ZG_D void block_sum(typename MsmOps<F>::Pt& total, typename MsmOps<F>::Pt* sh /* [128] */) {
+struct SpreadLds {
+  typename MsmOps<F>::PtMem park[256 / MsmOps<F>::LP];
+  typename MsmOps<F>::Own fold[4][MsmOps<F>::SL];
+};
+
+// Sum of `count` points by the 256 lanes of a workgroup (every lane must call); own(i) is this lane's part of point
+// i.  Groups of SL lanes stride over the points, then the groups fold: inside each wave by shuffles, across the
+// four waves through `fold`.  The sum is valid in the first SL lanes of the workgroup.
+template <class F, class OwnOf>
+ZG_D typename MsmOps<F>::Own wg_spread_sum(uint32_t count, OwnOf own, typename MsmOps<F>::Own (*fold)[MsmOps<F>::SL]) {
   using O = MsmOps<F>;
-  const uint32_t tid = threadIdx.x;
-  for (uint32_t stride = 128; stride >= (uint32_t)O::LP; stride >>= 1) {
-    if (tid >= stride && tid < 2 * stride) sh[tid - stride] = total;
-    __syncthreads();
-    if (stride >= 64) {
-      if (tid < stride) O::add(total, sh[tid]);  // whole waves add or sit out
-    } else if (tid < 64) {
-      // the levels inside the first wave: every lane runs the addition, the lanes outside the tree repeat logical
-      // thread 0's and drop the result (a wave that runs a group addition with part of its lanes switched off
-      // takes several times longer over it -- see k_split_sums)
-      const bool in_tree = tid < stride;
-      const typename O::Pt total0 = O::first_thread(total);
-      typename O::Pt x = in_tree ? total : total0;
-      O::add(x, sh[in_tree ? tid : tid % O::LP]);
-      if (in_tree) total = x;
-    }
-    __syncthreads();
+  constexpr uint32_t SL = O::SL, GW = 64 / SL, G = 256 / SL;  // groups per wave, per workgroup
+  const uint32_t g = threadIdx.x / SL, gw = g % GW, wave = threadIdx.x / 64, sub = threadIdx.x % SL;
+  typename O::Own acc = O::own_inf();
+  for (uint32_t i = g; i < count; i += G) O::own_add(acc, own(i));
+  // the fold starts at the first level that still has a point in its upper half
+  const uint32_t n_act = count < G ? count : G;  // groups that hold a point
+  uint32_t top = GW;
+  if (n_act < GW) {
+    top = 1;
+    while (top < n_act) top <<= 1;
   }
+#pragma unroll 1
+  for (uint32_t d = top / 2; d >= 1; d >>= 1) {
+    const typename O::Own o = O::own_shfl_down(acc, (int)(d * SL));
+    O::own_add_if(acc, o, gw < d);
+  }
+  if (n_act > GW) {  // (the same in every lane of the workgroup)
+    if (gw == 0) fold[wave][sub] = acc;
+    __syncthreads();
+    if (wave == 0) {
+      acc = g < 4 ? fold[g][sub] : O::own_inf();
+#pragma unroll 1
+      for (uint32_t d = 2; d >= 1; d >>= 1) {
+        const typename O::Own o = O::own_shfl_down(acc, (int)(d * SL));
+        O::own_add_if(acc, o, gw < d);
+      }
+    }
+    __syncthreads();  // `fold` may be written again by the caller's next sum
+  }
+  return acc;
 }
 
-// One workgroup per heavy bucket (grid-stride over heavy_list): logical threads stride over the
-// bucket's pieces, then the workgroup tree-adds through LDS.
+// Sum of the accumulators the logical threads of a workgroup hold (one lane, or lane pair, per point): each parks
+// its point in LDS and the workgroup adds them in the spread form.  Valid in the first SL lanes.
+template <class F>
+ZG_D typename MsmOps<F>::Own block_sum_spread(const typename MsmOps<F>::Pt& total, SpreadLds<F>& lds) {
+  using O = MsmOps<F>;
+  O::store(lds.park + threadIdx.x / O::LP, total);
+  __syncthreads();
+  const typename O::Own r = wg_spread_sum<F>(256 / O::LP, [&](uint32_t i) { return O::own_load(lds.park + i); }, lds.fold);
+  __syncthreads();  // `park` may be written again
+  return r;
+}
+
+// The buckets k_combine left: a bucket in thousands of pieces (the few buckets of a narrow top window, the small
+// values of a witness) is a long chain for one workgroup, so with fewer heavy buckets than workgroups every bucket
+// is cut into S slices, one workgroup each: its logical threads stride over the slice's pieces, the workgroup adds
+// them in the spread form, and the workgroup that finishes a bucket's last slice (a counter per bucket, zero at
+// launch) adds the S slice sums.  No workgroup waits for another.  slice_sum and slices_done hold gridDim.x slots.
 template <class F>
 __global__ __launch_bounds__(256, kMinWaves<F>) void k_heavy(const uint32_t* __restrict__ heavy_count,
                                                                const uint32_t* __restrict__ heavy_list,
                                                                const uint32_t* __restrict__ off, uint32_t nb,
                                                                uint32_t lanes,
                                                                const typename MsmOps<F>::PtMem* __restrict__ pts1,
-                                                               typename MsmOps<F>::PtMem* __restrict__ bucket_sum) {
+                                                               typename MsmOps<F>::PtMem* __restrict__ bucket_sum,
+                                                               typename MsmOps<F>::PtMem* slice_sum,
+                                                               uint32_t* __restrict__ slices_done) {
   using O = MsmOps<F>;
-  __shared__ typename O::Pt sh[128];
+  __shared__ SpreadLds<F> lds;
+  __shared__ uint32_t finished_bucket;
   const uint32_t n = *heavy_count;
+  if (!n) return;
+  const uint32_t S = n < gridDim.x ? gridDim.x / n : 1;
   const uint32_t e0 = off[0];
   const uint32_t K = chunk_len(off[nb] - e0, lanes, nb);
   const uint32_t lt = threadIdx.x / O::LP, nlt = 256 / O::LP;
-  for (uint32_t h = blockIdx.x; h < n; h += gridDim.x) {
+  for (uint32_t item = blockIdx.x; item < n * S; item += gridDim.x) {  // (S > 1: at most one item per workgroup)
+    const uint32_t h = item / S, slice = item % S;
     const uint32_t b = heavy_list[h];
     const uint32_t s = off[b] - e0, e = off[b + 1] - e0;
     const uint32_t pieces = (e - 1) / K - s / K + 1;
     typename O::Pt acc = O::inf();
-    for (uint32_t p = lt; p < pieces; p += nlt) O::add(acc, O::load(pts1 + piece_slot(s, K, p)));
-    block_sum<F>(acc, sh);
-    if (lt == 0) O::store(bucket_sum + b, acc);
+    for (uint32_t p = slice * nlt + lt; p < pieces; p += S * nlt) O::add(acc, O::load(pts1 + piece_slot(s, K, p)));
+    const typename O::Own sum = block_sum_spread<F>(acc, lds);
+    if (S == 1) {
+      if (threadIdx.x < O::SL) O::own_store(bucket_sum + b, sum);
+      continue;
+    }
+    if (threadIdx.x < O::SL) O::own_store(slice_sum + item, sum);
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) finished_bucket = atomicAdd(&slices_done[h], 1u) == S - 1;
+    __syncthreads();
+    if (finished_bucket) {  // (the same in every lane of the workgroup)
+      __threadfence();
+      const typename O::Own total =
+          wg_spread_sum<F>(S, [&](uint32_t i) { return O::own_load_fresh(slice_sum + (size_t)h * S + i); }, lds.fold);
+      if (threadIdx.x < O::SL) O::own_store(bucket_sum + b, total);
+    }
   }
 }
 
@@ -623,7 +679,7 @@ __global__ __launch_bounds__(256, kMinWaves<F>) void k_heavy(const uint32_t* __r
 // the host finishes (msm_collect) -- a CPU core adds points an order of magnitude faster than one
 // wave does, and the device part is two launches of log-depth sums.
 //
-// k_split_sums: each wave produces one output point.  Array a of set blockIdx.z holds count[a] =
+// k_split_sums: each workgroup produces one output point (wg_spread_sum).  Array a of set blockIdx.z holds count[a] =
 // r[a] * h[a] points at in + set*in_stride + in_off[a]; outputs are r[a] column sums (index mod r)
 // followed by h[a] row sums (index div r) at out_off[a].  With out_std the outputs are written in
 // the library-wide XYZZ form for the host instead.
@@ -639,43 +695,25 @@ __global__ __launch_bounds__(256, kMinWaves<F>) void k_split_sums(const typename
                                                                     typename MsmOps<F>::PtMem* __restrict__ out,
                                                                     XYZZ<F>* __restrict__ out_std) {
   using O = MsmOps<F>;
-  constexpr uint32_t LT = 64 / O::LP;  // logical threads per wave
+  __shared__ typename O::Own fold[4][O::SL];
   const uint32_t a = blockIdx.y, set = blockIdx.z;
   const uint32_t r = ss.r[a], h = ss.h[a];
-  const uint32_t task = blockIdx.x * 4 + threadIdx.x / 64;  // wave-uniform
+  const uint32_t task = blockIdx.x;
   if (task >= r + h) return;
-  const uint32_t lt = (threadIdx.x & 63) / O::LP;
   const typename O::PtMem* X = in + (size_t)set * ss.in_stride + ss.in_off[a];
-  typename O::Pt acc = O::inf();
+  typename O::Own acc;
   if (task < r) {
-    for (uint32_t k = lt; k < h; k += LT) O::add(acc, O::load(X + (size_t)k * r + task));
+    acc = wg_spread_sum<F>(h, [&](uint32_t k) { return O::own_load(X + (size_t)k * r + task); }, fold);
   } else {
     const typename O::PtMem* row = X + (size_t)(task - r) * r;
-    for (uint32_t k = lt; k < r; k += LT) O::add(acc, O::load(row + k));
+    acc = wg_spread_sum<F>(r, [&](uint32_t k) { return O::own_load(row + k); }, fold);
   }
-  // the fold starts at the first level that still has a point in its upper half (r and h are powers of two): a
-  // second-level array of 16 points would otherwise spend two of its six dependent additions on identities
-  const uint32_t count = task < r ? h : r;
-  // Every lane of the wave runs every addition: the lanes outside the fold repeat logical thread 0's (and drop the
-  // result).  Measured: with the addition under `if (lt < d)` a fold of four levels took 110 us, with every lane
-  // adding 50-65 us -- a wave whose lanes leave the addition at different points runs it several times slower than
-  // one that goes through it whole.
-#pragma unroll 1
-  for (uint32_t d = (count < LT ? count : LT) / 2; d >= 1; d >>= 1) {
-    const typename O::Pt o = O::shfl_down(acc, d * O::LP);
-    const bool in_fold = lt < d;
-    const typename O::Pt acc0 = O::first_thread(acc), o0 = O::first_thread(o);  // (shuffles: every lane takes part)
-    typename O::Pt x = in_fold ? acc : acc0;
-    const typename O::Pt y = in_fold ? o : o0;
-    O::add(x, y);
-    if (in_fold) acc = x;
-  }
-  if (lt == 0) {
+  if (threadIdx.x < O::SL) {
     const size_t dst = (size_t)set * ss.out_stride + ss.out_off[a] + task;
     if (out_std)
-      O::store_std(out_std + dst, acc);
+      O::own_store_std(out_std + dst, acc);
     else
-      O::store(out + dst, acc);
+      O::own_store(out + dst, acc);
   }
 }
 
@@ -684,12 +722,10 @@ template <class F>
 __global__ __launch_bounds__(256, kTailWaves) void k_sum_partials(const typename MsmOps<F>::PtMem* __restrict__ part,
                                                                       uint32_t count, XYZZ<F>* __restrict__ out_std) {
   using O = MsmOps<F>;
-  __shared__ typename O::Pt sh[128];
-  const uint32_t w = blockIdx.x, lt = threadIdx.x / O::LP, nlt = 256 / O::LP;
-  typename O::Pt acc = O::inf();
-  for (uint32_t i = lt; i < count; i += nlt) O::add(acc, O::load(part + ((size_t)w * count + i)));
-  block_sum<F>(acc, sh);
-  if (lt == 0) O::store_std(out_std + w, acc);
+  __shared__ typename O::Own fold[4][O::SL];
+  const uint32_t w = blockIdx.x;
+  const typename O::Own acc = wg_spread_sum<F>(count, [&](uint32_t i) { return O::own_load(part + ((size_t)w * count + i)); }, fold);
+  if (threadIdx.x < O::SL) O::own_store_std(out_std + w, acc);
 }
 
 // Plain sum of the bases whose scalar equals one, group blockIdx.y: the entries are
@@ -701,7 +737,7 @@ __global__ __launch_bounds__(256, kMinWaves<F>) void k_sum_range(JobTable<F> jt,
                                                                    typename MsmOps<F>::PtMem* __restrict__ part,
                                                                    uint32_t* __restrict__ err_flag) {
   using O = MsmOps<F>;
-  __shared__ typename O::Pt sh[128];
+  __shared__ SpreadLds<F> lds;
   const uint32_t g = blockIdx.y, lt = threadIdx.x / O::LP, nlt = 256 / O::LP;
   const uint32_t lo = off[nb + g], hi = off[nb + g + 1];
   const uint32_t nthreads = gridDim.x * nlt, t = blockIdx.x * nlt + lt;
@@ -716,8 +752,8 @@ __global__ __launch_bounds__(256, kMinWaves<F>) void k_sum_range(JobTable<F> jt,
     else
       *err_flag = 1;
   }
-  block_sum<F>(acc, sh);
-  if (lt == 0) O::store(part + ((size_t)g * gridDim.x + blockIdx.x), acc);
+  const typename O::Own sum = block_sum_spread<F>(acc, lds);
+  if (threadIdx.x < O::SL) O::own_store(part + ((size_t)g * gridDim.x + blockIdx.x), sum);
 }
 
 
@@ -758,7 +794,7 @@ __global__ __launch_bounds__(256, kTailWaves) void k_direct_sum(JobTable<F> jt, 
                                                                     typename MsmOps<F>::PtMem* __restrict__ part,
                                                                     uint32_t* __restrict__ err_flag) {
   using O = MsmOps<F>;
-  __shared__ typename O::Pt sh[128];
+  __shared__ SpreadLds<F> lds;
   const int j = blockIdx.y;
   const uint32_t n = jt.start[j + 1] - jt.start[j];
   const uint32_t lt = threadIdx.x / O::LP, nlt = 256 / O::LP;
@@ -794,8 +830,8 @@ __global__ __launch_bounds__(256, kTailWaves) void k_direct_sum(JobTable<F> jt, 
       w++;
     }
   }
-  block_sum<F>(acc, sh);
-  if (lt == 0) O::store(part + ((size_t)j * gridDim.x + blockIdx.x), acc);
+  const typename O::Own sum = block_sum_spread<F>(acc, lds);
+  if (threadIdx.x < O::SL) O::own_store(part + ((size_t)j * gridDim.x + blockIdx.x), sum);
 }
 
 // table[w*stride + i] = 2^(c*w) * table[i] for w in 1..W-1, every window in the internal packed form
@@ -1221,6 +1257,8 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
   const size_t o_cur = o;    o += align((size_t)ncount * 4);
   const size_t o_coff = o;   o += align((size_t)(nbins + 1) * 4);
   const size_t o_err = o;    o += 256;  // [0] identity-base flag, [2] number of heavy buckets
+  constexpr uint32_t HEAVY_GRID = 256;
+  const size_t o_done = o;   o += align(HEAVY_GRID * 4);  // k_heavy: slices finished, per heavy bucket
   const size_t o_zero_end = o;
   const size_t o_rec0 = o;   o += align(max_entries * sizeof(uint2));  // coarse-sorted entries
   const size_t o_rec = o;    o += align(max_entries * sizeof(uint2));  // bucket-sorted entries
@@ -1230,6 +1268,7 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
   using PtMem = typename MsmOps<F>::PtMem;
   const size_t o_pts1 = o;   o += align(2 * (size_t)lanes * sizeof(PtMem));
   const size_t o_heavy = o;  o += align((size_t)sh.nb * 4);
+  const size_t o_slice = o;  o += align(HEAVY_GRID * sizeof(PtMem));
   const size_t o_bsum = o;   o += align((size_t)sh.nb * sizeof(PtMem));
   const size_t o_mid = o;    o += align((size_t)nsets * fold.mid() * sizeof(PtMem));
   const size_t o_wstd = o;   o += align(nresult * sizeof(XYZZ<F>));  // the result block for the host
@@ -1341,7 +1380,8 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
     constexpr int L = 4;
     k_combine<F, L><<<(unsigned)(((size_t)sh.nb * L * LP + 255) / 256), 256, 0, st>>>(
         sh.nb, lanes, walk_off, pts1, bsum, err + 2, (uint32_t*)(base + o_heavy));
-    k_heavy<F><<<256, 256, 0, st>>>(err + 2, (const uint32_t*)(base + o_heavy), walk_off, sh.nb, lanes, pts1, bsum);
+    k_heavy<F><<<HEAVY_GRID, 256, 0, st>>>(err + 2, (const uint32_t*)(base + o_heavy), walk_off, sh.nb, lanes, pts1, bsum,
+                                           (PtMem*)(base + o_slice), (uint32_t*)(base + o_done));
   }
   {
     KernelTimer kt(ctx, is_g2 ? K_MSM_REDUCE_G2 : K_MSM_REDUCE_G1, (double)sh.nb, st);
@@ -1351,7 +1391,7 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
     s1.h[0] = 1u << fold.lH;
     s1.in_stride = sh.B;
     s1.out_stride = fold.mid();
-    k_split_sums<F><<<dim3((fold.mid() + 3) / 4, 1, nsets), 256, 0, st>>>(bsum, s1, mid, nullptr);
+    k_split_sums<F><<<dim3(fold.mid(), 1, nsets), 256, 0, st>>>(bsum, s1, mid, nullptr);
     SplitShape s2 = {};
     s2.narr = 2;
     s2.r[0] = 1u << fold.lr1;
@@ -1363,7 +1403,7 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
     s2.in_stride = fold.mid();
     s2.out_stride = fold.leaves();
     const uint32_t t2 = s2.r[0] + s2.h[0] > s2.r[1] + s2.h[1] ? s2.r[0] + s2.h[0] : s2.r[1] + s2.h[1];
-    k_split_sums<F><<<dim3((t2 + 3) / 4, 2, nsets), 256, 0, st>>>(mid, s2, nullptr, wstd);
+    k_split_sums<F><<<dim3(t2, 2, nsets), 256, 0, st>>>(mid, s2, nullptr, wstd);
   }
   ZG_HIP(ctx, hipGetLastError());
   if (ms.side)

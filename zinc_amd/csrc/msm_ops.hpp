@@ -6,6 +6,10 @@
 //   Aff     an affine base as one lane holds it
 //   LP      lanes that cooperate on one point (kernels index logical threads as lane / LP)
 //
+// The spread form, for the dependent additions that end a multiexp (see quad_add): a point lies over SL adjacent
+// lanes and every lane keeps its part (Own) only.  own_* are the operations on it; every lane of a group of SL
+// lanes must take part in each of them.
+//
 // Bases are read from the "internal packed" form the key tables are stored in (to_internal).
 #pragma once
 #include "curve29.hpp"
@@ -14,6 +18,10 @@ namespace zg {
 
 template <class F>
 struct MsmOps;
+
+// a word as another workgroup of this launch last wrote it (after its fence), not a copy that this compute unit's
+// vector cache may still hold
+ZG_D uint32_t load_fresh(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // G1: 29-bit-limb field (fp29.hpp), one lane per point.  Packed bases are in radix-2^261
 // Montgomery form, i.e. the ABI's radix-2^256 value times 32.
@@ -71,6 +79,33 @@ struct MsmOps<Fq> {
     }
     return a;
   }
+
+  // spread form: lane q of a quad holds coordinate q of (X, Y, ZZ, ZZZ)
+  static constexpr int SL = 4;
+  using Own = Fq29;
+  ZG_D static Own own_inf() { return Fq29::zero(); }
+  ZG_D static Own own_load(const PtMem* p) { return ((const Fq29*)p)[threadIdx.x & 3]; }
+  ZG_D static Own own_load_fresh(const PtMem* p) {
+    Own r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = load_fresh(((const Fq29*)p)[threadIdx.x & 3].v + i);
+    return r;
+  }
+  ZG_D static void own_store(PtMem* p, const Own& v) { ((Fq29*)p)[threadIdx.x & 3] = v; }
+  ZG_D static Own own_of(const Pt& p) { return quad_own(p); }  // p whole in every lane of the quad
+  ZG_D static void own_add(Own& a, const Own& b) { quad_add(a, b); }
+  // a += b in the groups where `active` holds; every lane of the wave walks the addition either way
+  ZG_D static void own_add_if(Own& a, const Own& b, bool active) { quad_add(a, pick(active, b, Fq29::zero())); }
+  ZG_D static Own own_shfl_down(const Own& v, int lanes) {
+    Own o;
+#pragma unroll
+    for (int i = 0; i < 9; i++) o.v[i] = __shfl_down(v.v[i], lanes);
+    return o;
+  }
+  ZG_D static void own_store_std(XYZZ<Fq>* dst, const Own& v) {
+    const bool inf = quad_is_inf(v);
+    ((Fq*)dst)[threadIdx.x & 3] = inf ? Fq::zero() : to_r256<Fq29Params, FqParams>(v);
+  }
 };
 
 // G2: the same 29-bit-limb field with every Fq2 value spread over a lane pair (even lane: real
@@ -127,6 +162,32 @@ struct MsmOps<Fq2> {
     c[2 + sub()] = inf ? Fq::zero() : to_r256<Fq29Params, FqParams>(p.y);
     c[4 + sub()] = inf ? Fq::zero() : to_r256<Fq29Params, FqParams>(p.zz);
     c[6 + sub()] = inf ? Fq::zero() : to_r256<Fq29Params, FqParams>(p.zzz);
+  }
+  // spread form: lane 2 pos + comp of an octet holds component comp of the coordinate at position pos (oct_add)
+  static constexpr int SL = 8;
+  using Own = Fq29;
+  ZG_D static Own own_inf() { return Fq29::zero(); }
+  ZG_D static const Fq29* own_slot(const PtMem* p) { return (const Fq29*)&p->half[sub()] + oct_coord(oct_pos()); }
+  ZG_D static Own own_load(const PtMem* p) { return *own_slot(p); }
+  ZG_D static Own own_load_fresh(const PtMem* p) {
+    Own r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = load_fresh(own_slot(p)->v + i);
+    return r;
+  }
+  ZG_D static void own_store(PtMem* p, const Own& v) { *(Fq29*)own_slot(p) = v; }
+  ZG_D static Own own_of(const Pt& p) { return oct_own(p); }  // p whole in every lane pair of the octet
+  ZG_D static void own_add(Own& a, const Own& b) { oct_add(a, b); }
+  ZG_D static void own_add_if(Own& a, const Own& b, bool active) { oct_add(a, pick(active, b, Fq29::zero())); }
+  ZG_D static Own own_shfl_down(const Own& v, int lanes) {
+    Own o;
+#pragma unroll
+    for (int i = 0; i < 9; i++) o.v[i] = __shfl_down(v.v[i], lanes);
+    return o;
+  }
+  ZG_D static void own_store_std(XYZZ<Fq2>* dst, const Own& v) {
+    const bool inf = oct_is_inf(v);
+    ((Fq*)dst)[2 * oct_coord(oct_pos()) + sub()] = inf ? Fq::zero() : to_r256<Fq29Params, FqParams>(v);
   }
   ZG_HD static Affine<Fq2> to_internal(Affine<Fq2> a) {
     for (int k = 0; k < 5; k++) {

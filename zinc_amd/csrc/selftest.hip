@@ -86,6 +86,33 @@ __global__ __launch_bounds__(64) void k_group_op_msm(int op, const Affine<F>* p,
   O::store_std(out + i, acc);
 }
 
+// op 7: P + (2q - q), op 8: 2 P + 2 (2q - q), through the spread form of the sums that end a multiexp (MsmOps::own_add): SL lanes per point,
+// each holding its part of both operands.
+template <class F>
+__global__ __launch_bounds__(64) void k_group_op_spread(int op, const Affine<F>* p, const Affine<F>* q, XYZZ<F>* out, uint32_t n) {
+  using O = MsmOps<F>;
+  const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) / O::SL;
+  if (i >= n) return;  // (whole groups leave)
+  typename O::Pt acc = O::inf(), t = O::inf();
+  typename O::Aff a;
+  if (O::load_base(p + i, false, &a)) O::madd(acc, a);
+  if (O::load_base(q + i, false, &a)) {
+    O::madd(t, a);
+    t = O::dbl(t);
+    O::load_base(q + i, true, &a);
+    O::madd(t, a);
+  }
+  typename O::Own x = O::own_of(acc);
+  O::own_add(x, O::own_of(t));
+  if (op == 8) {  // (p + q) + q, then + p: sums of the spread form as operands
+    O::own_add(x, O::own_of(t));
+    typename O::Own y = O::own_of(acc);
+    O::own_add(y, x);
+    x = y;
+  }
+  O::own_store_std(out + i, x);
+}
+
 // The two sides of the G2 subgroup test in the lane-pair arithmetic: op 4: [6x^2] P, op 5: psi(P) (q = the two psi
 // constants as one affine "point" (psi_x, psi_y) in the packed base form).
 __global__ __launch_bounds__(64) void k_g2_endo_msm(int op, const Affine<Fq2>* p, const Affine<Fq2>* consts, XYZZ<Fq2>* out, uint32_t n) {
@@ -140,12 +167,12 @@ static zg16_status run_group_msm(zg16_ctx* ctx, int op, const uint64_t* p, const
   const size_t pa = (pb + 255) & ~(size_t)255, qa = (qb + 255) & ~(size_t)255;
   ZG_TRY(scratch_get(ctx, 5, pa + qa + ob + 256, (void**)&buf));
   ZG_HIP(ctx, hipMemcpyAsync(buf, p, pb, hipMemcpyHostToDevice, ctx->stream));
-  if (op != 0 && op < 4) ZG_HIP(ctx, hipMemcpyAsync(buf + pa, q, qb, hipMemcpyHostToDevice, ctx->stream));
+  if ((op != 0 && op < 4) || op >= 7) ZG_HIP(ctx, hipMemcpyAsync(buf + pa, q, qb, hipMemcpyHostToDevice, ctx->stream));
   ZG_TRY(msm_build_table<F>(ctx, (Affine<F>*)buf, n, 0));
-  if (op == 1 || op == 2) ZG_TRY(msm_build_table<F>(ctx, (Affine<F>*)(buf + pa), n, 0));
+  if (op == 1 || op == 2 || op >= 7) ZG_TRY(msm_build_table<F>(ctx, (Affine<F>*)(buf + pa), n, 0));
   const unsigned lanes = (unsigned)n * MsmOps<F>::LP;
   if constexpr (sizeof(F) > sizeof(Fq)) {
-    if (op >= 4) {
+    if (op >= 4 && op <= 6) {
       // the psi constants, as one packed "point"
       Affine<Fq2> k = {g2_subgroup_consts().psi_x, g2_subgroup_consts().psi_y};
       k = MsmOps<Fq2>::to_internal(k);
@@ -154,6 +181,11 @@ static zg16_status run_group_msm(zg16_ctx* ctx, int op, const uint64_t* p, const
       k_g2_endo_msm<<<(lanes + 63) / 64, 64, 0, ctx->stream>>>(op, (const Affine<Fq2>*)buf, (const Affine<Fq2>*)(buf + pa),
                                                               (XYZZ<Fq2>*)(buf + pa + qa), (uint32_t)n);
     }
+  }
+  if (op >= 7) {
+    const unsigned spread_lanes = (unsigned)n * MsmOps<F>::SL;
+    k_group_op_spread<F><<<(spread_lanes + 63) / 64, 64, 0, ctx->stream>>>(op, (const Affine<F>*)buf, (const Affine<F>*)(buf + pa),
+                                                                         (XYZZ<F>*)(buf + pa + qa), (uint32_t)n);
   }
   if (op < 4)
     k_group_op_msm<F><<<(lanes + 63) / 64, 64, 0, ctx->stream>>>(op, (const Affine<F>*)buf, buf + pa,
@@ -217,7 +249,8 @@ zg16_status zg16_selftest_field(zg16_ctx* ctx, int field, int op, const uint64_t
 zg16_status zg16_selftest_group(zg16_ctx* ctx, int group, int op, const uint64_t* p, const uint64_t* q, size_t n,
                                 uint64_t* out) {
   const bool endo = group == 4 && (op >= 4 && op <= 6);  // the G2 subgroup test: its two sides, its kernel
-  if (!ctx || !p || !out || !n || op < 0 || (op > 3 && !endo) || (op && !endo && !q) || n > (1u << 24))
+  const bool spread = (group == 3 || group == 4) && (op == 7 || op == 8);  // the addition of the sums that end a multiexp
+  if (!ctx || !p || !out || !n || op < 0 || (op > 3 && !endo && !spread) || (op && !endo && !q) || n > (1u << 24))
     return zg::fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "bad selftest arguments");
   ZG_HIP(ctx, hipSetDevice(ctx->device));
   if (group == 1) return zg::run_group<zg::Fq>(ctx, op, p, q, n, out);
