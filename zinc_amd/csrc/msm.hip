@@ -22,12 +22,14 @@
 //                          skewed witness (zinc witnesses are mostly 0/1 bits) cannot unbalance
 //                          the launch.  A run inside one chunk finishes its bucket; a run cut by a
 //                          chunk edge leaves a partial sum in slot 2t / 2t+1.
-//   4. k_combine         : four lanes per bucket add the pieces of a bucket cut at chunk edges (at
-//                          most 32 of them) and fold by shuffles; larger buckets get one workgroup
-//                          each in k_heavy.
+//   4. k_combine         : the pieces of a bucket cut at chunk edges (at most 32 of them) are added by four lanes
+//                          (G2: eight) that hold one point between them; larger buckets get one or more
+//                          workgroups each in k_heavy.
 //   5. k_sum_range       : plain tree sum for scalars equal to one (about half of a zinc witness);
 //                          they reach their bucket through a wave-aggregated counter, not a digit.
 //   6. k_split_sums x2   : each bucket set folded to a few dozen plain sums (no scalar multiplications)
+//      Steps 4-6 are chains of dependent additions on few points: they run in the spread form of quad_add /
+//      oct_add (a point over 4 / 8 lanes, the products of an addition four at a time).
 //   7. host              : sum_b (b+1)*S_b from the folded sums; Horner over the W window sums
 //                          (per-window layout only)
 #define ZG_OUTLINE_FIELD_MUL 1
@@ -511,10 +513,9 @@ __global__ __launch_bounds__(256, kMinWaves<F>) void k_accumulate(JobTable<F> jt
   if (cur != KEY_INVALID) flush();
 }
 
-// L adjacent logical threads per bucket add the pieces level 0 left of a bucket it cut at chunk edges,
-// then fold across the threads by shuffles.  Buckets in more than LIGHT_PIECES pieces are appended to
-// heavy_list for k_heavy.
-template <class F, int L>
+// One group of SL lanes per bucket adds, in the spread form, the pieces level 0 left of a bucket it cut at chunk
+// edges.  Buckets in more than LIGHT_PIECES pieces are appended to heavy_list for k_heavy.
+template <class F>
 __global__ __launch_bounds__(256, kMinWaves<F>) void k_combine(uint32_t nb, uint32_t lanes,
                                                                  const uint32_t* __restrict__ off,
                                                                  const typename MsmOps<F>::PtMem* __restrict__ pts1,
@@ -522,35 +523,21 @@ __global__ __launch_bounds__(256, kMinWaves<F>) void k_combine(uint32_t nb, uint
                                                                  uint32_t* __restrict__ heavy_count,
                                                                  uint32_t* __restrict__ heavy_list) {
   using O = MsmOps<F>;
-  const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) / O::LP;
-  const uint32_t b = t / L, sub = t % L;
+  const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) / O::SL;
+  if (b >= nb) return;  // (whole groups leave)
   const uint32_t e0 = off[0];  // positions below are counted from the first entry of this launch's buckets
   const uint32_t K = chunk_len(off[nb] - e0, lanes, nb);
-  uint32_t s = 0, pieces = 0;  // pieces == 0: nothing to add here
-  if (b < nb) {
-    s = off[b] - e0;
-    const uint32_t e = off[b + 1] - e0;
-    if (e > s) {
-      const uint32_t n = (e - 1) / K - s / K + 1;
-      if (n > LIGHT_PIECES) {
-        if (sub == 0 && (threadIdx.x % O::LP) == 0) heavy_list[atomicAdd(heavy_count, 1u)] = b;
-      } else if (n > 1) {  // n == 1: level 0 finished the bucket inside one chunk
-        pieces = n;
-      }
-    }
+  const uint32_t s = off[b] - e0, e = off[b + 1] - e0;
+  if (e <= s) return;
+  const uint32_t pieces = (e - 1) / K - s / K + 1;
+  if (pieces == 1) return;  // level 0 finished the bucket inside one chunk
+  if (pieces > LIGHT_PIECES) {
+    if (threadIdx.x % O::SL == 0) heavy_list[atomicAdd(heavy_count, 1u)] = b;
+    return;
   }
-  typename O::Pt acc = O::inf();
-  for (uint32_t p = sub; p < pieces; p += L) O::add(acc, O::load(pts1 + piece_slot(s, K, p)));
-  if (L > 1) {
-    // the threads of one bucket are adjacent in the wave and all of them reach this point
-    if (__ballot(pieces != 0) != 0) {
-      for (int d = L / 2; d >= 1; d >>= 1) {
-        const typename O::Pt o = O::shfl_down(acc, d * O::LP);
-        if (sub + d < L) O::add(acc, o);
-      }
-    }
-  }
-  if (pieces && sub == 0) O::store(bucket_sum + b, acc);
+  typename O::Own acc = O::own_load(pts1 + piece_slot(s, K, 0));
+  for (uint32_t p = 1; p < pieces; p++) O::own_add(acc, O::own_load(pts1 + piece_slot(s, K, p)));
+  O::own_store(bucket_sum + b, acc);
 }
 
 // p * k for a small unsigned k
@@ -624,10 +611,12 @@ ZG_D typename MsmOps<F>::Own block_sum_spread(const typename MsmOps<F>::Pt& tota
 }
 
 // The buckets k_combine left: a bucket in thousands of pieces (the few buckets of a narrow top window, the small
-// values of a witness) is a long chain for one workgroup, so with fewer heavy buckets than workgroups every bucket
-// is cut into S slices, one workgroup each: its logical threads stride over the slice's pieces, the workgroup adds
-// them in the spread form, and the workgroup that finishes a bucket's last slice (a counter per bucket, zero at
-// launch) adds the S slice sums.  No workgroup waits for another.  slice_sum and slices_done hold gridDim.x slots.
+// values of a witness) is a long chain for one workgroup, so with fewer heavy buckets than workgroups a bucket is cut
+// into slices of about HEAVY_PER_THREAD pieces per logical thread, one workgroup each: its threads stride over the
+// slice's pieces, the workgroup adds them in the spread form, and the workgroup that finishes a bucket's last slice (a
+// counter per bucket, zero at launch) adds the slice sums.  No workgroup waits for another; workgroups beyond a
+// bucket's slices leave at once.  slice_sum and slices_done hold gridDim.x slots.
+static constexpr uint32_t HEAVY_PER_THREAD = 6;
 template <class F>
 __global__ __launch_bounds__(256, kMinWaves<F>) void k_heavy(const uint32_t* __restrict__ heavy_count,
                                                                const uint32_t* __restrict__ heavy_list,
@@ -642,15 +631,18 @@ __global__ __launch_bounds__(256, kMinWaves<F>) void k_heavy(const uint32_t* __r
   __shared__ uint32_t finished_bucket;
   const uint32_t n = *heavy_count;
   if (!n) return;
-  const uint32_t S = n < gridDim.x ? gridDim.x / n : 1;
+  const uint32_t max_slices = n < gridDim.x ? gridDim.x / n : 1;
   const uint32_t e0 = off[0];
   const uint32_t K = chunk_len(off[nb] - e0, lanes, nb);
   const uint32_t lt = threadIdx.x / O::LP, nlt = 256 / O::LP;
-  for (uint32_t item = blockIdx.x; item < n * S; item += gridDim.x) {  // (S > 1: at most one item per workgroup)
-    const uint32_t h = item / S, slice = item % S;
+  for (uint32_t item = blockIdx.x; item < n * max_slices; item += gridDim.x) {  // (max_slices > 1: one item at most)
+    const uint32_t h = item / max_slices, slice = item % max_slices;
     const uint32_t b = heavy_list[h];
     const uint32_t s = off[b] - e0, e = off[b + 1] - e0;
     const uint32_t pieces = (e - 1) / K - s / K + 1;
+    uint32_t S = (pieces + nlt * HEAVY_PER_THREAD - 1) / (nlt * HEAVY_PER_THREAD);
+    if (S > max_slices) S = max_slices;
+    if (slice >= S) continue;
     typename O::Pt acc = O::inf();
     for (uint32_t p = slice * nlt + lt; p < pieces; p += S * nlt) O::add(acc, O::load(pts1 + piece_slot(s, K, p)));
     const typename O::Own sum = block_sum_spread<F>(acc, lds);
@@ -666,7 +658,7 @@ __global__ __launch_bounds__(256, kMinWaves<F>) void k_heavy(const uint32_t* __r
     if (finished_bucket) {  // (the same in every lane of the workgroup)
       __threadfence();
       const typename O::Own total =
-          wg_spread_sum<F>(S, [&](uint32_t i) { return O::own_load_fresh(slice_sum + (size_t)h * S + i); }, lds.fold);
+          wg_spread_sum<F>(S, [&](uint32_t i) { return O::own_load_fresh(slice_sum + (size_t)h * max_slices + i); }, lds.fold);
       if (threadIdx.x < O::SL) O::own_store(bucket_sum + b, total);
     }
   }
@@ -1377,8 +1369,7 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
   }
   {
     KernelTimer kt(ctx, is_g2 ? K_MSM_ACCN_G2 : K_MSM_ACCN_G1, (double)sh.nb, st);
-    constexpr int L = 4;
-    k_combine<F, L><<<(unsigned)(((size_t)sh.nb * L * LP + 255) / 256), 256, 0, st>>>(
+    k_combine<F><<<(unsigned)(((size_t)sh.nb * MsmOps<F>::SL + 255) / 256), 256, 0, st>>>(
         sh.nb, lanes, walk_off, pts1, bsum, err + 2, (uint32_t*)(base + o_heavy));
     k_heavy<F><<<HEAVY_GRID, 256, 0, st>>>(err + 2, (const uint32_t*)(base + o_heavy), walk_off, sh.nb, lanes, pts1, bsum,
                                            (PtMem*)(base + o_slice), (uint32_t*)(base + o_done));
