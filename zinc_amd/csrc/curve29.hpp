@@ -173,14 +173,19 @@ ZG_D bool quad_is_inf(const Fp29<P>& own) {
   return quad_perm<QUAD_B2>((uint32_t)own.is_zero_limbs()) != 0;
 }
 
-// a += b, both spread over the quad.  No branch on the common paths (identity operands are selected at the end), so
-// every lane of a wave walks the same instructions whatever its quad holds.
+// a += b, both spread over the quad.  No branch on the common paths but one that the whole wave takes together
+// (identity operands are selected at the end), so every lane of a wave walks the same instructions whatever its
+// quad holds.
 template <class P>
 ZG_D void quad_add(Fp29<P>& a, const Fp29<P>& b) {
   using F = Fp29<P>;
   const uint32_t c = threadIdx.x & 3;
   const bool hi = c >= 2;
   const bool ainf = quad_is_inf(a), binf = quad_is_inf(b);
+  if (__all(ainf || binf)) {  // no quad of the wave has two points to add (sums over empty ranges, thin trees)
+    a = pick(binf, a, b);
+    return;
+  }
   const F bx = quad_perm<QUAD_X2>(b);
   const F m1 = mul(a, bx);                          // u1 | s1 | u2 | s2 : 8*2, 5*2 -> <2
   const F mx = quad_perm<QUAD_X2>(m1);
@@ -374,6 +379,10 @@ ZG_D void oct_add(Fp29<P>& a, const Fp29<P>& b) {
   const uint32_t pos = oct_pos();
   const bool lo = pos < 2;
   const bool ainf = oct_is_inf(a), binf = oct_is_inf(b);
+  if (__all(ainf || binf)) {  // no octet of the wave has two points to add
+    a = pick(binf, a, b);
+    return;
+  }
   const F bxo = oct_mirror(b), bx = pair_swap(bxo);  // b's coordinate at 3 - pos: the partner's component, this lane's
   // u1 = X1 ZZ2 | s1 = Y1 ZZZ2 | s2 = ZZZ1 Y2 | u2 = ZZ1 X2 : 6 * (6 + 8) -> < 2 (the widest pairing bounds them all)
   const F m1 = mul_pair_x(a, pair_swap(a), bx, bxo, P::KS8);

@@ -732,6 +732,10 @@ __global__ __launch_bounds__(256, kMinWaves<F>) void k_sum_range(JobTable<F> jt,
   __shared__ SpreadLds<F> lds;
   const uint32_t g = blockIdx.y, lt = threadIdx.x / O::LP, nlt = 256 / O::LP;
   const uint32_t lo = off[nb + g], hi = off[nb + g + 1];
+  if (lo == hi) {  // no scalar of the group equals one (the h query's are uniform): nothing to add in any workgroup
+    if (threadIdx.x < O::SL) O::own_store(part + ((size_t)g * gridDim.x + blockIdx.x), O::own_inf());
+    return;
+  }
   const uint32_t nthreads = gridDim.x * nlt, t = blockIdx.x * nlt + lt;
   const uint32_t per = (hi - lo + nthreads - 1) / nthreads;
   const uint32_t a = lo + t * per < hi ? lo + t * per : hi;
