@@ -5,6 +5,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -52,6 +53,7 @@ struct zg16_ctx {
   void* pinned = nullptr;            // page-locked host memory for asynchronous result read-backs
   hipEvent_t ev[16] = {};
   std::string last_error = "";
+  std::mutex error_mutex;            // a sharded proof queues its witness multiexps from a second host thread
   std::map<unsigned, zg::NttDomain*> domains;  // per log2 size
   std::map<uint64_t, void*> cross_tables;      // twiddles of the cross-GPU step of a sharded transform
   std::map<uint64_t, void*> hshard_tables;     // strided factor tables of an H computation spread over GPUs
@@ -88,7 +90,10 @@ inline zg16_status fail(zg16_ctx* ctx, zg16_status st, const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(buf, sizeof buf, fmt, ap);
   va_end(ap);
-  if (ctx) ctx->last_error = buf;
+  if (ctx) {
+    std::lock_guard<std::mutex> lock(ctx->error_mutex);
+    ctx->last_error = buf;
+  }
   return st;
 }
 

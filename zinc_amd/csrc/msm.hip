@@ -940,6 +940,10 @@ uint32_t msm_table_window(size_t points, int role) {
   int c = (int)lg - (role == 0 ? 3 : 4);
   if (c < 8) c = 8;
   if (c > 20) c = 20;
+  // A width whose last window holds only a few of the scalar's 254 bits sends every term's top digit to a handful
+  // of buckets (c = 14: 19 windows, 2 bits in the last, four buckets with a quarter of the terms each): those are
+  // the heavy buckets of a uniform query.  Widen until the last window is at least half full.
+  while (c < 20 && 254 - ((255 + c - 1) / c - 1) * c < (c + 1) / 2) c++;
   return (uint32_t)c;
 }
 

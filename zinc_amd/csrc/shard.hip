@@ -53,8 +53,48 @@ struct zg16_hshard {
   MsmPending pend_g2, pend_z, pend_h;
   hipEvent_t ev_z = nullptr, ev_g2 = nullptr, ev_early = nullptr;
   int next_stage = 0;
+  // Stream-ordered proofs queue the ~50 launches of the witness multiexps from a second host thread: queued by the
+  // calling thread they keep it from the first exchange for about 0.4 ms, which the GPU's main stream -- the
+  // critical path -- spends idle (a rank's share of a 2^20-row proof on 8 GPUs is 1.3 ms of GPU work).
+  std::thread helper;
+  zg16_status helper_status = ZG16_OK;
+  uint64_t proofs = 0;  // the first proof sizes the scratch arenas and stays on one thread
   std::chrono::steady_clock::time_point t_begin;  // stage 0 entered (total_ms of zg16_last_timings: host clock, exchanges included)
 };
+
+// The multiexps over the witness (l, a, b_g1 in one launch; b_g2), queued on the context's early and aux streams
+// behind hs->ev_z.
+static zg16_status enqueue_witness_multiexps(zg16_hshard* hs, const Fr* z) {
+  zg16_ctx* ctx = hs->ctx;
+  const zg16_pk* pk = hs->pk;
+  const zg16_r1cs* r = hs->r;
+  char* pinned = (char*)ctx->pinned;
+  const uint32_t tc = pk->table_c;
+  // the witness launch sorts for b_g2 as well when the digit widths agree (see prove_partial_impl)
+  MsmSortShare share;
+  share.group = 2;
+  share.sorted = ctx->ev[10];
+  const bool try_share = tc == pk->table_c_g2 && pk->hi_b > pk->lo_b && !(getenv("ZG16_SHARE_SORT") && atoi(getenv("ZG16_SHARE_SORT")) == 0);
+  {
+    ZG_HIP(ctx, hipStreamWaitEvent(ctx->early_stream, hs->ev_z, 0));
+    const MsmJob<Fq> jobs_z[3] = {
+        {pk->l, z + r->n_in + pk->lo_l, nullptr, pk->hi_l - pk->lo_l, pk->hi_l - pk->lo_l, tc, 0, pk->l_d, pk->table_step},
+        {pk->a, z, r->a_map + pk->lo_a, pk->hi_a - pk->lo_a, pk->hi_a - pk->lo_a, tc, 1, pk->a_d, pk->table_step},
+        {pk->b1, z, r->b_map + pk->lo_b, pk->hi_b - pk->lo_b, pk->hi_b - pk->lo_b, tc, 2, pk->b1_d, pk->table_step}};
+    const MsmStreams ms = {ctx->early_stream, nullptr, nullptr, nullptr};
+    ZG_TRY(msm_launch<Fq>(ctx, ms, 6, pinned + 2 * MSM_PINNED_BYTES, jobs_z, 3, 3, &hs->pend_z, nullptr, try_share ? &share : nullptr));
+    ZG_HIP(ctx, hipEventRecord(hs->ev_early, ctx->early_stream));
+  }
+  {
+    ZG_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, hs->ev_z, 0));
+    MsmJob<Fq2> jb = {pk->b2, z, r->b_map + pk->lo_b, pk->hi_b - pk->lo_b, pk->hi_b - pk->lo_b, pk->table_c_g2, 0, pk->b2_d, pk->table_step};
+    const MsmStreams ms = {ctx->aux_stream, nullptr, nullptr, nullptr};
+    ZG_TRY(msm_launch<Fq2>(ctx, ms, 2, pinned + MSM_PINNED_BYTES, &jb, 1, 1, &hs->pend_g2, nullptr, nullptr,
+                           try_share && share.valid ? &share : nullptr));
+    ZG_HIP(ctx, hipEventRecord(hs->ev_g2, ctx->aux_stream));
+  }
+  return ZG16_OK;
+}
 
 extern "C" {
 
@@ -88,6 +128,7 @@ zg16_status zg16_hshard_create(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1cs
 
 void zg16_hshard_free(zg16_hshard* hs) {
   if (!hs) return;
+  if (hs->helper.joinable()) hs->helper.join();
   if (hs->ctx) {
     (void)hipSetDevice(hs->ctx->device);
     (void)hipDeviceSynchronize();
@@ -136,30 +177,14 @@ zg16_status zg16_hshard_stage(zg16_hshard* hs, int stage, const uint64_t* z_in, 
     ZG_TRY(spmv_blocks_device(ctx, r, z, tmp, tmp + L, tmp + 2 * L, log_blk, (uint32_t)L, hs->shard << log_blk, (uint32_t)L));
     for (int v = 0; v < 3; v++)
       ZG_TRY(ntt_cross_chunked(ctx, tmp + v * L, 0, work + v * blk, 3 * blk, hs->log_m, hs->log_g, hs->shard, true, nullptr));
-    char* pinned = (char*)ctx->pinned;
-    const uint32_t tc = pk->table_c;
-    // the witness launch sorts for b_g2 as well when the digit widths agree (see prove_partial_impl)
-    MsmSortShare share;
-    share.group = 2;
-    share.sorted = ctx->ev[10];
-    const bool try_share = tc == pk->table_c_g2 && pk->hi_b > pk->lo_b && !(getenv("ZG16_SHARE_SORT") && atoi(getenv("ZG16_SHARE_SORT")) == 0);
-    {
-      ZG_HIP(ctx, hipStreamWaitEvent(ctx->early_stream, hs->ev_z, 0));
-      const MsmJob<Fq> jobs_z[3] = {
-          {pk->l, z + r->n_in + pk->lo_l, nullptr, pk->hi_l - pk->lo_l, pk->hi_l - pk->lo_l, tc, 0, pk->l_d, pk->table_step},
-          {pk->a, z, r->a_map + pk->lo_a, pk->hi_a - pk->lo_a, pk->hi_a - pk->lo_a, tc, 1, pk->a_d, pk->table_step},
-          {pk->b1, z, r->b_map + pk->lo_b, pk->hi_b - pk->lo_b, pk->hi_b - pk->lo_b, tc, 2, pk->b1_d, pk->table_step}};
-      const MsmStreams ms = {ctx->early_stream, nullptr, nullptr, nullptr};
-      ZG_TRY(msm_launch<Fq>(ctx, ms, 6, pinned + 2 * MSM_PINNED_BYTES, jobs_z, 3, 3, &hs->pend_z, nullptr, try_share ? &share : nullptr));
-      ZG_HIP(ctx, hipEventRecord(hs->ev_early, ctx->early_stream));
-    }
-    {
-      ZG_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, hs->ev_z, 0));
-      MsmJob<Fq2> jb = {pk->b2, z, r->b_map + pk->lo_b, pk->hi_b - pk->lo_b, pk->hi_b - pk->lo_b, pk->table_c_g2, 0, pk->b2_d, pk->table_step};
-      const MsmStreams ms = {ctx->aux_stream, nullptr, nullptr, nullptr};
-      ZG_TRY(msm_launch<Fq2>(ctx, ms, 2, pinned + MSM_PINNED_BYTES, &jb, 1, 1, &hs->pend_g2, nullptr, nullptr,
-                             try_share && share.valid ? &share : nullptr));
-      ZG_HIP(ctx, hipEventRecord(hs->ev_g2, ctx->aux_stream));
+    if (hs->helper.joinable()) hs->helper.join();  // (a proof that was abandoned part-way)
+    hs->helper_status = ZG16_OK;
+    if (hs->stream_ordered && !ctx->profile && hs->proofs > 0) {
+      hs->helper = std::thread([hs, z] {
+        hs->helper_status = hipSetDevice(hs->ctx->device) == hipSuccess ? enqueue_witness_multiexps(hs, z) : ZG16_ERR_DEVICE;
+      });
+    } else {
+      ZG_TRY(enqueue_witness_multiexps(hs, z));
     }
     n_ex = 3;
   } else if (stage == 1) {
@@ -201,6 +226,8 @@ zg16_status zg16_hshard_finish(zg16_hshard* hs, zg16_partial* out) {
   if (hs->next_stage != 4) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "zg16_hshard_finish before stage 3");
   ZG_HIP(ctx, hipSetDevice(ctx->device));
   hs->next_stage = 0;
+  hs->proofs++;
+  if (hs->helper.joinable()) hs->helper.join();
   // let every pipeline drain before reading (or, on an error, before the caller can reuse what the kernels touch)
   const hipError_t e1 = hipStreamSynchronize(ctx->early_stream), e2 = hipStreamSynchronize(ctx->aux_stream),
                    e3 = hipStreamSynchronize(ctx->stream);
@@ -208,6 +235,7 @@ zg16_status zg16_hshard_finish(zg16_hshard* hs, zg16_partial* out) {
   ZG_HIP(ctx, e1);
   ZG_HIP(ctx, e2);
   ZG_HIP(ctx, e3);
+  ZG_TRY(hs->helper_status);
   ctx->timings = zg16_timings();
   ctx->timings.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - hs->t_begin).count();
   G1XYZZ g1[3], h_sum;
