@@ -1274,10 +1274,12 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
   const size_t o_wstd = o;   o += align(nresult * sizeof(XYZZ<F>));  // the result block for the host
   const uint32_t ntiles = (ncount + SCAN_TILE - 1) / SCAN_TILE;
   constexpr uint32_t LP = MsmOps<F>::LP;
-  // k_sum_range: sized so that a logical thread adds about 16 bases when half of a group's scalars equal one (a
-  // zinc witness): the workgroup tree that follows costs about a dozen additions per thread, so fewer bases per
-  // thread waste the launch on the tree (2 per thread: proof 3.5 % slower), many more make it a long serial tail
-  constexpr size_t ONES_PER_THREAD = 16;
+  // k_sum_range: sized so that a logical thread adds about 8 bases when half of a group's scalars equal one (a zinc
+  // witness): the workgroup sum that follows costs a few additions per thread, so far fewer bases per thread waste
+  // the launch on it and many more make a long serial tail (measured with the spread-form sum, same box: 4 / 8 / 12 /
+  // 16 per thread -> 1.204 / 1.213 / 1.236 / 1.248 ms at 2^17 rows, flat within noise at 2^20, 52.6 vs 52.4 ms for
+  // 8 vs 16 at 2^24)
+  constexpr size_t ONES_PER_THREAD = 8;
   const size_t ones_div = (size_t)sh.G * 2 * (256 / LP) * ONES_PER_THREAD;
   uint32_t ones_blocks = (uint32_t)((n + ones_div - 1) / ones_div);
   if (ones_blocks > 1024) ones_blocks = 1024;
