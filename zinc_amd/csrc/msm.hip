@@ -535,8 +535,14 @@ __global__ __launch_bounds__(256, kMinWaves<F>) void k_combine(uint32_t nb, uint
     if (threadIdx.x % O::SL == 0) heavy_list[atomicAdd(heavy_count, 1u)] = b;
     return;
   }
+  // (the next piece is on its way while the current one is added: the chain is one addition after another)
   typename O::Own acc = O::own_load(pts1 + piece_slot(s, K, 0));
-  for (uint32_t p = 1; p < pieces; p++) O::own_add(acc, O::own_load(pts1 + piece_slot(s, K, p)));
+  typename O::Own next = O::own_load(pts1 + piece_slot(s, K, 1));
+  for (uint32_t p = 1; p < pieces; p++) {
+    const typename O::Own cur = next;
+    if (p + 1 < pieces) next = O::own_load(pts1 + piece_slot(s, K, p + 1));
+    O::own_add(acc, cur);
+  }
   O::own_store(bucket_sum + b, acc);
 }
 
