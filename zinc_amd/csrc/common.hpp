@@ -51,6 +51,13 @@ struct zg16_ctx {
   hipStream_t side_stream = nullptr;   // side branch of the h multiexp (its unit-scalar sums)
   int cu_count = 256;
   void* pinned = nullptr;            // page-locked host memory for asynchronous result read-backs
+  // staging of a witness handed over in pageable host memory (zg::copy_witness_from_host): STAGE_THREADS x 2
+  // page-locked buffers of STAGE_CHUNK bytes, allocated at the first such proof, and the event behind each
+  static constexpr int STAGE_THREADS = 8;
+  static constexpr size_t STAGE_CHUNK = (size_t)1 << 20;
+  void* stage = nullptr;
+  hipEvent_t stage_ev[2 * STAGE_THREADS] = {};
+  bool stage_busy[2 * STAGE_THREADS] = {};
   hipEvent_t ev[16] = {};
   std::string last_error = "";
   std::mutex error_mutex;            // a sharded proof queues its witness multiexps from a second host thread

@@ -121,6 +121,8 @@ struct zg16_pk {
 namespace zg {
 // Release a handle whoever owns it (zg16_pk_free / zg16_r1cs_free skip handles the cache owns).
 // Device witness z = z_in || z_aux (scratch slot 3 of the context), copied on the context's stream.
+// `bytes` of a witness in host memory to `dst` on the GPU, queued on the context's stream (see api.hip)
+zg16_status copy_witness_from_host(zg16_ctx* ctx, void* dst, const void* src, size_t bytes);
 zg16_status stage_witness(zg16_ctx* ctx, const zg16_r1cs* r, const uint64_t* z_in, const uint64_t* z_aux, int on_device,
                           Fr** z_out);
 zg16_status check_key_fits(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1cs* r);
