@@ -147,6 +147,31 @@ def g2_add(a, p):
     return Pt(x3, y3, mul_pair(mul_pair(a.zz, p.zz, 2), pp, 2), mul_pair(mul_pair(a.zzz, p.zzz, 2), ppp, 2))
 
 
+def g1_quad_add(a, p):
+    """quad_add (curve29.hpp): the steps of g1_add, four products at a time; lane 3's last product goes through the
+    fused scan with a zero subtrahend"""
+    m1 = [mul(a.x, p.zz), mul(a.y, p.zzz), mul(a.zz, p.x), mul(a.zzz, p.y)]
+    d = [sub_k(m1[2], m1[0], 3), sub_k(m1[3], m1[1], 3)]
+    m2 = [mul(d[0], d[0]), mul(d[1], d[1]), mul(a.zz, p.zz), mul(a.zzz, p.zzz)]
+    m3 = [mul(m1[0], m2[0]), mul(d[0], m2[0]), mul(m2[2], m2[0])]
+    x3 = sub2_k(m2[1], m3[1], m3[0], 6); t = sub_k(m3[0], x3, 8)
+    y3 = mul_sub(d[1], t, m1[1], m3[1], 2)
+    zzz3 = mul_sub(m2[3], m3[1], m1[3], ZERO, 2)
+    return Pt(x3, y3, m3[2], zzz3)
+
+
+def g2_oct_add(a, p):
+    """oct_add: round 1 pairs every coordinate with the widest constant, round 4 is one plain product per position"""
+    m1 = [mul_pair(a.x, p.zz, 8), mul_pair(a.y, p.zzz, 8), mul_pair(a.zzz, p.y, 8), mul_pair(a.zz, p.x, 8)]
+    d = [sub_k(m1[3], m1[0], 2), sub_k(m1[2], m1[1], 2)]
+    m2 = [mul_pair(d[0], d[0], 4), mul_pair(d[1], d[1], 4), mul_pair(a.zzz, p.zzz, 4), mul_pair(a.zz, p.zz, 4)]
+    m3 = [mul_pair(m1[0], m2[0], 2), mul_pair(d[0], m2[0], 2), mul_pair(m2[3], m2[0], 2)]
+    x3 = sub2_k(m2[1], m3[1], m3[0], 4); t = sub_k(m3[0], x3, 6)
+    m4 = [mul_pair(m1[1], m3[1], 4), mul_pair(t, d[1], 4), mul_pair(m2[2], m3[1], 4)]
+    y3 = sub_k(m4[1], m4[0], 2)
+    return Pt(x3, y3, m3[2], m4[2])
+
+
 def join(a, b):
     return Pt(*[V(max(p.v, q.v), max(p.L, q.L)) for p, q in
                 zip((a.x, a.y, a.zz, a.zzz), (b.x, b.y, b.zz, b.zzz))])
@@ -157,7 +182,8 @@ def fixed_point(first, madd, add, dbl, base_y, stored_x, stored_y):
     cur = first
     for _ in range(20):
         nxt = join(cur, madd(cur, base_x, base_y))
-        nxt = join(nxt, add(cur, cur))
+        for f in add:
+            nxt = join(nxt, f(cur, cur))
         nxt = join(nxt, dbl(cur))
         same = all(abs(p.v - q.v) < 1e-9 for p, q in zip((cur.x, cur.y, cur.zz, cur.zzz),
                                                          (nxt.x, nxt.y, nxt.zz, nxt.zzz)))
@@ -175,12 +201,12 @@ def main():
     one = V(1.0, STRICT)
     # G1: the base's y may be 3p - y (negated digit), normalised
     g1_first = Pt(V(1.0, STRICT), V(3.0, NORM), one, one)
-    r = fixed_point(g1_first, g1_madd, g1_add, g1_dbl, V(3.0, NORM), 8.0, 5.0)
+    r = fixed_point(g1_first, g1_madd, (g1_add, g1_quad_add), g1_dbl, V(3.0, NORM), 8.0, 5.0)
     print("G1 stored bounds: X < %.2fp  Y < %.2fp  ZZ < %.2fp  ZZZ < %.2fp" % (r.x.v, r.y.v, r.zz.v, r.zzz.v))
     # G2 on lane pairs: canonical bases (negation is done on the packed form)
     g2_first = Pt(one, one, one, one)
     g2_dbl_affine(one, one)
-    r = fixed_point(g2_first, g2_madd, g2_add, g2_dbl, one, 6.0, 4.0)
+    r = fixed_point(g2_first, g2_madd, (g2_add, g2_oct_add), g2_dbl, one, 6.0, 4.0)
     print("G2 stored bounds: X < %.2fp  Y < %.2fp  ZZ < %.2fp  ZZZ < %.2fp (per component)" % (r.x.v, r.y.v, r.zz.v, r.zzz.v))
     # radix change for the host: to_r256 multiplies a stored coordinate by a canonical constant
     mul(V(8.0, NORM), one)
