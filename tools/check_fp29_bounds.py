@@ -48,6 +48,27 @@ def mul_pair(a, b, ks):
     return V(1 + C * s, STRICT)
 
 
+def sqr_pair(a, k, limit=169.0):
+    """complex squaring on a lane pair: (a0 + a1) * norm(a0 + K - a1) | (2 a0) * a1, one product per lane"""
+    assert a.L <= K_MIN and k >= a.v + MARGIN, "K does not dominate"
+    assert a.L + K_MAX < 1 << 32
+    assert 9 * (2 * a.L) * NORM + 9 * STRICT * STRICT + (1 << 36) < 1 << 64, "column overflow"
+    s = 2 * a.v * (a.v + k)
+    assert s <= limit, "squaring operands too large: %.1f" % s
+    return V(1 + C * s, STRICT)
+
+
+def mul_sub_pair(a, b, kb, c, kc, d):
+    """a*b - c*d over Fq2 in one scan; the negations norm(K - .) are formed by sub_k"""
+    sub_k(ZERO, b, kb); sub_k(ZERO, c, kc)
+    for x in (a, b, c, d):
+        assert x.L <= NORM, "operands must be normalised"
+    assert 4 * 9 * NORM * NORM + 9 * STRICT * STRICT + (1 << 36) < 1 << 64, "column overflow"
+    s = a.v * (b.v + kb) + 2 * kc * d.v
+    assert s <= 169.0, "fused pair product operands too large: %.1f" % s
+    return V(1 + C * s, STRICT)
+
+
 def mul_sub(a, b, c, d, ks):
     """a*b + (KS - c)*d in one column scan with one reduction"""
     assert c.L <= KS_MIN, "KS does not dominate limbs"
@@ -129,12 +150,13 @@ def g2_dbl_affine(bx, by):
 
 def g2_madd(acc, bx, by):
     u2 = mul_pair(acc.zz, bx, 2); s2 = mul_pair(acc.zzz, by, 2)
-    pp_ = sub_k(u2, acc.x, 6); pp = mul_pair(pp_, pp_, 8)
+    pp_ = sub_k(u2, acc.x, 6); pp = sqr_pair(pp_, 8, limit=220.0)   # below 2.3p: its users take KS3
+    assert pp.v < 3 - MARGIN
     r = sub_k(s2, acc.y, 4)
-    ppp = mul_pair(pp_, pp, 2); q = mul_pair(acc.x, pp, 2)
-    x3 = sub2_k(mul_pair(r, r, 6), ppp, q, 4); t = sub_k(q, x3, 6)
-    y3 = sub_k(mul_pair(t, r, 6), mul_pair(acc.y, ppp, 2), 2)
-    return Pt(x3, y3, mul_pair(acc.zz, pp, 2), mul_pair(acc.zzz, ppp, 2))
+    ppp = mul_pair(pp_, pp, 3); q = mul_pair(acc.x, pp, 3)
+    x3 = sub2_k(sqr_pair(r, 6), ppp, q, 4); t = sub_k(q, x3, 6)
+    y3 = mul_sub_pair(t, r, 6, acc.y, 4, ppp)
+    return Pt(x3, y3, mul_pair(acc.zz, pp, 3), mul_pair(acc.zzz, ppp, 2))
 
 
 def g2_add(a, p):

@@ -269,8 +269,10 @@ ZG_D void add_mixed_pair(XYZZ29<P>& acc, const Affine29<P>& p) {
   const F u2 = mul_pair(acc.zz, p.x, P::KS2);       // 2*3
   const F s2 = mul_pair(acc.zzz, p.y, P::KS2);
   const F pp_ = sub_k(u2, acc.x, P::K6);            // <7.1
-  const F pp = mul_pair(pp_, pp_, P::KS8);          // 7.1*15.1 = 107 -> <1.64
-  if (pair_both(is_zero_mod_p(pp))) {               // same x: doubling or cancellation (rare)
+  // the two squares by the complex squaring (one product per lane each); P^2 comes out below 2.27p -- real
+  // component 14.2 * 15.1 = 214 -- and its three users take it with the next constant up
+  const F pp = sqr_pair(pp_, P::K8);                // <2.27
+  if (pair_both(is_zero_mod_p3(pp))) {              // same x: doubling or cancellation (rare)
     const F r0 = sub_k(s2, acc.y, P::K4);
     if (pair_both(is_zero_mod_p(mul_pair(r0, r0, P::KS6))))
       acc = dbl_affine_pair(p);
@@ -279,14 +281,15 @@ ZG_D void add_mixed_pair(XYZZ29<P>& acc, const Affine29<P>& p) {
     return;
   }
   const F r = sub_k(s2, acc.y, P::K4);              // <5.1
-  const F ppp = mul_pair(pp_, pp, P::KS2);          // 7.1*3.64
-  const F q = mul_pair(acc.x, pp, P::KS2);          // 6*3.64
-  const F x3 = sub2_k(mul_pair(r, r, P::KS6), ppp, q, P::K4);  // 5.1*11.1 = 57 -> <1.34 ; ppp + 2q < 3.5 ; <5.4
+  const F ppp = mul_pair(pp_, pp, P::KS3);          // 7.1*5.27
+  const F q = mul_pair(acc.x, pp, P::KS3);          // 6*5.27
+  const F x3 = sub2_k(sqr_pair(r, P::K6), ppp, q, P::K4);  // 10.2*11.1 = 113 -> <1.67 ; ppp + 2q < 3.7 ; <5.7
   const F t = sub_k(q, x3, P::K6);                  // <7.2
-  const F y3 = sub_k(mul_pair(t, r, P::KS6), mul_pair(acc.y, ppp, P::KS2), P::K2);  // 7.2*11.1 = 80 ; <3.5
+  // t r - Y ppp in one scan: 7.2 * (5.1 + 6) + 2 * 4 * 1.3 = 90
+  const F y3 = mul_sub_pair(t, r, sub_k(F::zero(), r, P::K6), acc.y, sub_k(F::zero(), acc.y, P::K4), ppp);
   acc.x = x3;
   acc.y = y3;
-  acc.zz = mul_pair(acc.zz, pp, P::KS2);
+  acc.zz = mul_pair(acc.zz, pp, P::KS3);
   acc.zzz = mul_pair(acc.zzz, ppp, P::KS2);
 }
 

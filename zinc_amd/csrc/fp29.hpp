@@ -267,6 +267,86 @@ ZG_D Fp29<P> mul_pair(const Fp29<P>& a, const Fp29<P>& b, const uint32_t (&KS)[9
   return mul_pair_x(a, pair_swap(a), b, pair_swap(b), KS);
 }
 
+// This lane's component of a^2 by the complex squaring (a0 + a1)(a0 - a1) + 2 a0 a1 u: ONE product per lane (162
+// multiply-adds against mul_pair's 243).  K (one of P::K*) dominates a's components limb by limb; the result is
+// below (1 + C s) p with s = 2 (bound of a) * (bound of a + K / p), which may exceed 169 (the callers say how far).
+template <class P>
+ZG_D Fp29<P> sqr_pair(const Fp29<P>& a, const uint32_t (&K)[9]) {
+  const bool im = (threadIdx.x & 1) != 0;
+  const Fp29<P> ao = pair_swap(a);
+  Fp29<P> x, y;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    x.v[i] = im ? 2 * ao.v[i] : a.v[i] + ao.v[i];          // a0 + a1 | 2 a0
+    y.v[i] = im ? a.v[i] : a.v[i] + K[i] - ao.v[i];        // a0 - a1 | a1
+  }
+  return mul(x, norm(y));
+}
+
+// This lane's component of a*b - c*d over Fq2 as ONE column scan with one Montgomery reduction (405 multiply-adds
+// against 486 for two products).  nb and nc are component-wise negations of b and c, norm(K - .) for any multiple K
+// of p that dominates them; every operand has normalised limbs.  Result below 2p when
+// (bound of a) * (bound of b + K_b / p) + 2 (K_c / p) (bound of d) <= 169.
+template <class P>
+ZG_D Fp29<P> mul_sub_pair(const Fp29<P>& a, const Fp29<P>& b, const Fp29<P>& nb, const Fp29<P>& c, const Fp29<P>& nc,
+                          const Fp29<P>& d) {
+  const bool im = (threadIdx.x & 1) != 0;
+  const Fp29<P> ao = pair_swap(a), bo = pair_swap(b), nbo = pair_swap(nb), co = pair_swap(c), nco = pair_swap(nc),
+                dd = pair_swap(d);
+  // real: a0 b0 + a1 (-b1) + (-c0) d0 + c1 d1        imaginary: a1 b0 + a0 b1 + (-c1) d0 + (-c0) d1
+  uint32_t v1[9], v2[9], v3[9], u4[9], v4[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    v1[i] = im ? bo.v[i] : b.v[i];     // times a
+    v2[i] = im ? b.v[i] : nbo.v[i];    // times ao
+    v3[i] = im ? dd.v[i] : d.v[i];     // times nc
+    u4[i] = im ? nco.v[i] : co.v[i];
+    v4[i] = im ? d.v[i] : dd.v[i];     // times u4
+  }
+  uint32_t m[9];
+  Fp29<P> r;
+  uint64_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < 17; k++) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      const int j = k - i;
+      if (j >= 0 && j < 9) {
+        acc = mad64(a.v[i], v1[j], acc);
+        acc = mad64(ao.v[i], v2[j], acc);
+        acc = mad64(nc.v[i], v3[j], acc);
+        acc = mad64(u4[i], v4[j], acc);
+      }
+    }
+    if (k < 9) {
+#pragma unroll
+      for (int i = 0; i < k; i++) acc = mad64(m[i], P::MOD[k - i], acc);
+      m[k] = ((uint32_t)acc * P::INV) & MASK29;
+      acc = mad64(m[k], P::MOD[0], acc);
+    } else {
+#pragma unroll
+      for (int i = k - 8; i < 9; i++) acc = mad64(m[i], P::MOD[k - i], acc);
+      r.v[k - 9] = (uint32_t)acc & MASK29;
+    }
+    acc >>= 29;
+  }
+  r.v[8] = (uint32_t)acc;
+  return r;
+}
+
+// Is the product-normalised value a (below 3p, limbs strictly below 2^29) zero modulo p?
+template <class P>
+ZG_D bool is_zero_mod_p3(const Fp29<P>& a) {
+  uint32_t z = 0, e = 0, f = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    z |= a.v[i];
+    e |= a.v[i] ^ P::MOD[i];
+    f |= a.v[i] ^ P::MOD2[i];
+  }
+  return z == 0 || e == 0 || f == 0;
+}
+
 // Is the product-normalised value a (below 2p, limbs strictly below 2^29) zero modulo p?
 template <class P>
 ZG_D bool is_zero_mod_p(const Fp29<P>& a) {
