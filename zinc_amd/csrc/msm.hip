@@ -1125,8 +1125,8 @@ struct FoldShape {
   uint32_t leaves() const { return (1u << lr1) + (1u << lh1) + (1u << lr2) + (1u << lh2); }
 };
 
-// Result block in page-locked host memory: [0] identity-base flag, [1] entry count, then
-// sets * leaves XYZZ points (the folded bucket sets) and one unit-scalar sum per group.
+// Result block in page-locked host memory: the launch's 256 bytes of flags ([0] identity base met, [3] entry count),
+// then sets * leaves XYZZ points (the folded bucket sets) and one unit-scalar sum per group.
 static constexpr size_t PINNED_POINTS = 256;
 
 template <class F>
@@ -1181,8 +1181,9 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
     uint32_t blocks = (uint32_t)((largest * DIRECT_W + per_block - 1) / per_block);
     if (blocks > 1024) blocks = 1024;
     auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t o_part = 256, o_out = o_part + align((size_t)nj * blocks * sizeof(PtMem));
-    const size_t need = o_out + align((size_t)nj * sizeof(XYZZ<F>));
+    // flags (256 bytes) and results lie back to back and go to the host in one copy
+    const size_t o_out = PINNED_POINTS, o_part = o_out + align((size_t)nj * sizeof(XYZZ<F>));
+    const size_t need = o_part + align((size_t)nj * blocks * sizeof(PtMem));
     char* base;
     if (fixed) {
       // a caller-supplied workspace: nothing is allocated (the per-kernel timers create events, so they stay off)
@@ -1204,8 +1205,7 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
       k_sum_partials<F><<<nj, 256, 0, st>>>(part, blocks, wstd);
     }
     ZG_HIP(ctx, hipGetLastError());
-    ZG_HIP(ctx, hipMemcpyAsync(pinned, err, 8, hipMemcpyDeviceToHost, st));
-    ZG_HIP(ctx, hipMemcpyAsync((char*)pinned + PINNED_POINTS, wstd, (size_t)nj * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
+    ZG_HIP(ctx, hipMemcpyAsync(pinned, base, PINNED_POINTS + (size_t)nj * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
     pend->nsets = 1;
     pend->direct = 1;
     pend->acc_kernel = sizeof(F) > sizeof(Fq) ? K_MSM_ACC0_G2 : K_MSM_ACC0_G1;
@@ -1262,10 +1262,13 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
   const size_t o_off = o;    o += align((size_t)(ncount + 1) * 4);
   const size_t o_cur = o;    o += align((size_t)ncount * 4);
   const size_t o_coff = o;   o += align((size_t)(nbins + 1) * 4);
-  const size_t o_err = o;    o += 256;  // [0] identity-base flag, [2] number of heavy buckets
   constexpr uint32_t HEAVY_GRID = 256;
   const size_t o_done = o;   o += align(HEAVY_GRID * 4);  // k_heavy: slices finished, per heavy bucket
+  // [0] identity-base flag, [2] number of heavy buckets, [3] entry count; the result block follows it directly, so
+  // that flags and results go to the host in one copy
+  const size_t o_err = o;    o += PINNED_POINTS;
   const size_t o_zero_end = o;
+  const size_t o_wstd = o;   o += align(nresult * sizeof(XYZZ<F>));  // the result block for the host
   const size_t o_rec0 = o;   o += align(max_entries * sizeof(uint2));  // coarse-sorted entries
   const size_t o_rec = o;    o += align(max_entries * sizeof(uint2));  // bucket-sorted entries
   // k_accumulate runs a fixed number of logical threads: one full round of the GPU at four waves per SIMD.
@@ -1277,7 +1280,6 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
   const size_t o_slice = o;  o += align(HEAVY_GRID * sizeof(PtMem));
   const size_t o_bsum = o;   o += align((size_t)sh.nb * sizeof(PtMem));
   const size_t o_mid = o;    o += align((size_t)nsets * fold.mid() * sizeof(PtMem));
-  const size_t o_wstd = o;   o += align(nresult * sizeof(XYZZ<F>));  // the result block for the host
   const uint32_t ntiles = (ncount + SCAN_TILE - 1) / SCAN_TILE;
   constexpr uint32_t LP = MsmOps<F>::LP;
   // k_sum_range: sized so that a logical thread adds about 8 bases when half of a group's scalars equal one (a zinc
@@ -1417,9 +1419,7 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
     ZG_HIP(ctx, hipStreamWaitEvent(st, ms.ev_join, 0));
   else
     ZG_TRY(unit_sums(st));
-  ZG_HIP(ctx, hipMemcpyAsync(pinned, err, 4, hipMemcpyDeviceToHost, st));
-  ZG_HIP(ctx, hipMemcpyAsync((char*)pinned + 4, err + 3, 4, hipMemcpyDeviceToHost, st));
-  ZG_HIP(ctx, hipMemcpyAsync((char*)pinned + PINNED_POINTS, wstd, nresult * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
+  ZG_HIP(ctx, hipMemcpyAsync(pinned, err, PINNED_POINTS + nresult * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
   pend->nsets = nsets;
   pend->acc_kernel = is_g2 ? K_MSM_ACC0_G2 : K_MSM_ACC0_G1;
   pend->c = sh.c;
@@ -1475,7 +1475,7 @@ zg16_status msm_collect(zg16_ctx* ctx, const MsmPending* pend, XYZZ<F>* out) {
     for (uint32_t g = 0; g < pend->ngroups; g++) out[g] = sums[g];
     return ZG16_OK;
   }
-  if (ctx->profile) ctx->kstat[pend->acc_kernel].units += head[1];
+  if (ctx->profile) ctx->kstat[pend->acc_kernel].units += head[3];
   const XYZZ<F>* hw = (const XYZZ<F>*)((const char*)pend->pinned + PINNED_POINTS);
   const FoldShape fold(pend->c - 1);
   const XYZZ<F>* ones = hw + (size_t)pend->nsets * fold.leaves();
