@@ -562,6 +562,10 @@ def main():
     # rank on GPU 0, exchanges staged through the host)
     backend = os.environ.get("ZG16_DIST_BACKEND", "nccl")
     local_rank = int(os.environ.get("LOCAL_RANK", "0")) if backend == "nccl" else 0
+    if world > 1 and backend == "nccl":
+        # a rank runs the context's four streams AND the collectives' stream: with the default of four hardware
+        # queues per process two of them share a queue and the later one waits behind the earlier one's kernels
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
@@ -577,11 +581,13 @@ def main():
     ctx.graph({"auto": None, "on": True, "off": False}[args.graph])
     n_rows = 1 << args.log_rows
 
+    sharded_ok = [True]  # cleared when the headline's sharded proof fails its check below
+
     def split_for(log_rows):
         """False (every rank repeats the transforms), True (A/B/C chains on three ranks) or "sharded"."""
         if world == 1 or args.split_transforms == "off":
             return False
-        can_shard = world in (2, 4, 8) and log_rows >= 2 * (world.bit_length() - 1) + 1
+        can_shard = sharded_ok[0] and world in (2, 4, 8) and log_rows >= 2 * (world.bit_length() - 1) + 1
         if args.split_transforms == "sharded":
             return "sharded" if can_shard else False
         if args.split_transforms == "on":
@@ -592,6 +598,28 @@ def main():
 
     t0 = time.time()
     case = ProveCase(ctx, d, args.log_rows, args.dense, split_for(args.log_rows))
+    schedule_fallback = None
+    if world > 1 and case.split == "sharded":
+        # The sharded schedule's exchanges have only ever run between contexts of one GPU: prove once and check the
+        # proof with the verifier before anything is timed; a rank that fails (or a proof that does not verify) sends
+        # every rank back to the replicated schedule, and the line says so.
+        ok, why = 1.0, ""
+        try:
+            if os.environ.get("ZG16_BENCH_FAIL_SHARDED"):  # rehearsal of the way back
+                raise RuntimeError("ZG16_BENCH_FAIL_SHARDED is set")
+            proof = case.step()
+            if rank == 0:
+                from zinc_amd.fields import mont_to_ints, R_MOD
+                from zinc_amd.groth16 import verify_proof
+                ok = 1.0 if verify_proof(case.params, proof, mont_to_ints(np.asarray(case.zi)[1:], R_MOD)) else 0.0
+                why = "" if ok else "the sharded proof did not verify"
+        except Exception as e:  # noqa: BLE001
+            ok, why = 0.0, "%s: %s" % (type(e).__name__, e)
+        if d.max_over_ranks(1.0 - ok) > 0.0:
+            schedule_fallback = why or "another rank failed"
+            sharded_ok[0] = False
+            case.free()
+            case = ProveCase(ctx, d, args.log_rows, args.dense, False)
     setup_s = time.time() - t0
     params, r1cs, key, mat, zi, za = case.params, case.r1cs, case.key, case.mat, case.zi, case.za
     split = case.split
@@ -732,7 +760,8 @@ def main():
             "config": {"workload": "synthetic zinc-shaped R1CS, 2^%d rows (%s witness), full Groth16 prove incl. G2 multiexp"
                                    % (args.log_rows, "dense" if args.dense else "80% bit"),
                        "n_inputs": int(r1cs.n_inputs), "n_aux": int(r1cs.n_aux), "nnz": [int(m[1].shape[0]) for m in r1cs.mats],
-                       "a_aux_density": dens[0], "b_aux_density": dens[2], "parallelism": "msm-point-range x%d%s" % (world, ", transforms sharded over all ranks" if split == "sharded" else ", A/B/C transform chains on 3 ranks" if split else "")},
+                       "a_aux_density": dens[0], "b_aux_density": dens[2], "parallelism": "msm-point-range x%d%s" % (world, ", transforms sharded over all ranks" if split == "sharded" else ", A/B/C transform chains on 3 ranks" if split else ""),
+                       **({"schedule_fallback": "sharded schedule abandoned for the replicated one: " + schedule_fallback} if schedule_fallback else {})},
             "constraints_per_s": n_rows / (ms_per_step / 1e3),
             "stage_ms_last_step": stage,
             "kernels": per_kernel,
