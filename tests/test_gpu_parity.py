@@ -271,6 +271,32 @@ def test_msm_golden(gpu_ctx, name, group):
     assert from_m(fn(to_m([p for p, d in zip(bases, dens) if d]), sc, dens))[0] == unhex(fx["result_density"])
 
 
+@pytest.mark.parametrize("group", ["g1", "g2"])
+def test_msm_closing_sums_at_group_boundaries(gpu_ctx, group):
+    """The sums that end a multiexp run with a point spread over 4 (G1) / 8 (G2) lanes: lane groups stride over the
+    points, fold inside a wave and across the four waves of a workgroup.  Term counts on both sides of every one of
+    those boundaries (1 .. 257 unit scalars: only the unit-scalar sums run; then small scalars: heavy buckets)
+    against the CPU oracle."""
+    from oracle import cpu_binding as cb
+    from zinc_amd import workload
+    rng = np.random.default_rng(77)
+    g1gen, g2gen = workload._generators()
+    one = ints_to_mont([1], R_MOD)[0]
+    fn = gpu_ctx.msm_g1 if group == "g1" else gpu_ctx.msm_g2
+    sizes = (1, 2, 3, 4, 5, 15, 16, 17, 31, 33, 63, 64, 65, 127, 129, 255, 256, 257, 700) if group == "g1" else (1, 2, 3, 7, 8, 9, 31, 32, 33, 127, 128, 129, 300)
+    top = max(sizes)
+    ks = rand_fr(rng, top)
+    all_bases = workload.fixed_base_g1(gpu_ctx, g1gen, ks) if group == "g1" else workload.fixed_base_g2(gpu_ctx, g2gen, ks)
+    for n in sizes:
+        bases = np.ascontiguousarray(all_bases[:n])
+        sc = np.tile(one, (n, 1))
+        st, want = cb.multiexp(group, bases, sc, None, threads=4)
+        assert st == 0 and np.array_equal(fn(bases, sc), want), "unit scalars, n = %d" % n
+    small = ints_to_mont([int(v) for v in rng.integers(2, 6, size=top)], R_MOD)
+    st, want = cb.multiexp(group, all_bases, small, None, threads=4)
+    assert st == 0 and np.array_equal(fn(all_bases, small), want)
+
+
 def test_msm_edge_cases(gpu_ctx):
     from oracle import bn254 as O
     G = O.G1_GEN

@@ -185,7 +185,7 @@ class ResidentBases:
         return out
 
     def free(self):
-        if self.handle:
+        if self.handle and self.ctx.handle:  # (a handle that outlives its context is not touched again: the library would follow a dangling context pointer)
             self.ctx._lib.zg16_bases_free(self.handle)
             self.handle = C.c_void_p()
 
@@ -291,7 +291,7 @@ class DeviceKey:
         return v
 
     def free(self):
-        if self.handle and not getattr(self, "_borrowed", False):
+        if self.handle and self.ctx.handle and not getattr(self, "_borrowed", False):
             self.ctx._lib.zg16_pk_free(self.handle)
         self.handle = C.c_void_p()
 
@@ -379,7 +379,7 @@ class DeviceR1CS:
         return outs
 
     def free(self):
-        if self.handle and not getattr(self, "_borrowed", False):
+        if self.handle and self.ctx.handle and not getattr(self, "_borrowed", False):
             self.ctx._lib.zg16_r1cs_free(self.handle)
         self.handle = C.c_void_p()
 
