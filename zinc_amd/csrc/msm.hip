@@ -133,7 +133,8 @@ ZG_D uint32_t extract_bits(const uint32_t* v, uint32_t lo, uint32_t c) {
 // atomics are per (workgroup, bin) instead of per entry:
 //   k_sort_count    terms -> digits -> LDS histogram of coarse bins (bucket >> shift, at most
 //                   SORT_MAX_COARSE of them) -> the workgroup's row of the (bin, workgroup) histogram
-//   k_coarse_offsets  coarse bin starts, read off the scanned per-workgroup histograms
+//                   (the coarse bin starts are read off the scanned per-workgroup histograms by the first
+//                   workgroup of the next kernel)
 //   k_sort_scatter  same digits again; a scan of the per-workgroup histograms k_sort_count left behind gives
 //                   the workgroup its run in every coarse bin, and it writes its entries there (ranks by LDS
 //                   atomics, no global atomic at all).  Unit scalars go straight to their final
@@ -237,10 +238,10 @@ __global__ __launch_bounds__(256) void k_sort_count(JobTable<F> jt, MsmShape sh,
 // The coarse offsets fall out of the scanned per-workgroup histograms: bin j starts where its first workgroup's run
 // starts.  coff[nbins] = total, and hist[nb + g] = number of unit scalars of group g so that the bucket scan places
 // them too.  (A global histogram kept by atomics beside the per-workgroup ones cost k_sort_count half its time: a
-// thousand workgroups adding to the same few hundred counters.)
-__global__ __launch_bounds__(256) void k_coarse_offsets(const uint32_t* __restrict__ wg_off, uint32_t sgrid, uint32_t n_wgh,
-                                                        uint32_t ncoarse, uint32_t G, uint32_t* __restrict__ coff,
-                                                        uint32_t* __restrict__ hist, uint32_t nb) {
+// thousand workgroups adding to the same few hundred counters.)  Done by the first workgroup of k_sort_scatter on its
+// way in -- a launch of its own was one more link in a chain of launches.
+ZG_D void coarse_offsets(const uint32_t* __restrict__ wg_off, uint32_t sgrid, uint32_t n_wgh, uint32_t ncoarse, uint32_t G,
+                         uint32_t* __restrict__ coff, uint32_t* __restrict__ hist, uint32_t nb) {
   const uint32_t nbins = ncoarse + G;
   for (uint32_t j = threadIdx.x; j <= nbins; j += 256) coff[j] = j < nbins ? wg_off[(size_t)j * sgrid] : wg_off[n_wgh];
   if (threadIdx.x < G) {
@@ -257,11 +258,13 @@ __global__ __launch_bounds__(256) void k_coarse_offsets(const uint32_t* __restri
 // 2^24.  The scatter is bound by its digit arithmetic, LDS atomics and barriers, not by HBM writes.)
 template <class F>
 __global__ __launch_bounds__(256) void k_sort_scatter(JobTable<F> jt, MsmShape sh, SortShape ss,
-                                                             const uint32_t* __restrict__ wg_off,
-                                                             uint2* __restrict__ rec_coarse, uint2* __restrict__ rec_final) {
+                                                             const uint32_t* __restrict__ wg_off, uint32_t n_wgh,
+                                                             uint2* __restrict__ rec_coarse, uint2* __restrict__ rec_final,
+                                                             uint32_t* __restrict__ coff, uint32_t* __restrict__ hist) {
   __shared__ uint32_t lh[SORT_MAX_COARSE + MAX_JOBS];     // cursor inside this workgroup's run of each bin
   __shared__ uint32_t lbase[SORT_MAX_COARSE + MAX_JOBS];  // start of that run (scanned k_sort_count histogram)
   const uint32_t tid = threadIdx.x, nbins = ss.ncoarse + sh.G;
+  if (blockIdx.x == 0) coarse_offsets(wg_off, gridDim.x, n_wgh, ss.ncoarse, sh.G, coff, hist, sh.nb);
   for (uint32_t j = tid; j < nbins; j += 256) {
     lh[j] = 0;
     lbase[j] = wg_off[(size_t)j * gridDim.x + blockIdx.x];
@@ -357,8 +360,8 @@ __global__ __launch_bounds__(256) void k_fine_scatter(const uint2* __restrict__ 
   }
 }
 
-// Exclusive scan of hist[0..count) into off[0..count] (and a copy in cursor[0..count)) in three
-// launches: per-workgroup scans of 4096 counters, a scan of the workgroup totals, a fix-up.
+// Exclusive scan of hist[0..count) into off[0..count] (and a copy in cursor[0..count)) in two
+// launches: per-workgroup scans of 4096 counters, then a fix-up by the sums of the tiles before.
 static constexpr uint32_t SCAN_TILE = 4096;
 
 // (hist and off may be the same array: a lane reads its sixteen counters before it writes them)
@@ -390,41 +393,37 @@ __global__ __launch_bounds__(256) void k_scan_local(const uint32_t* hist, uint32
   if (tid == 255) tile_sum[blockIdx.x] = part[255];
 }
 
-// One workgroup: exclusive scan of tile_sum[0..ntiles) in place; tile_sum[ntiles] = grand total.
-__global__ __launch_bounds__(1024) void k_scan_tiles(uint32_t* __restrict__ tile_sum, uint32_t ntiles) {
-  __shared__ uint32_t part[1024];
-  const uint32_t tid = threadIdx.x;
-  const uint32_t per = (ntiles + 1023) / 1024;
-  const uint32_t lo = tid * per, hi = (lo + per < ntiles) ? lo + per : ntiles;
-  uint32_t s = 0;
-  for (uint32_t i = lo; i < hi; i++) s += tile_sum[i];
-  part[tid] = s;
-  __syncthreads();
-  for (uint32_t d = 1; d < 1024; d <<= 1) {
-    uint32_t v = tid >= d ? part[tid - d] : 0;
-    __syncthreads();
-    part[tid] += v;
-    __syncthreads();
-  }
-  uint32_t run = tid ? part[tid - 1] : 0;
-  for (uint32_t i = lo; i < hi; i++) {
-    const uint32_t v = tile_sum[i];
-    tile_sum[i] = run;
-    run += v;
-  }
-  if (tid == 1023) tile_sum[ntiles] = part[1023];
-}
-
-// (cursor may be the same array as off)
+// Second and last launch of the scan: every workgroup adds up the sums of the tiles before its own (at most a few
+// hundred values -- cheaper than a launch of its own for a scan of them) and adds that to its 256 locally scanned
+// counters.  (cursor may be the same array as off.)
 __global__ __launch_bounds__(256) void k_scan_fixup(uint32_t* off, uint32_t* cursor, uint32_t count,
                                                     const uint32_t* __restrict__ tile_sum, uint32_t ntiles) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ uint32_t part[256];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t i = blockIdx.x * blockDim.x + tid;
+  // (SCAN_TILE is a multiple of the workgroup size: all of a workgroup's counters lie in one tile; the workgroup
+  // that holds index `count` needs every tile)
+  const uint32_t first = blockIdx.x * blockDim.x;
+  const uint32_t before = first >= count ? ntiles : first / SCAN_TILE;
+  uint32_t s = 0;
+  for (uint32_t t = tid; t < before; t += 256) s += tile_sum[t];
+  part[tid] = s;
+  __syncthreads();
+  for (uint32_t d = 128; d >= 1; d >>= 1) {
+    if (tid < d) part[tid] += part[tid + d];
+    __syncthreads();
+  }
+  const uint32_t base = part[0];
   if (i < count) {
-    const uint32_t v = off[i] + tile_sum[i / SCAN_TILE];
+    const uint32_t v = off[i] + base;
     off[i] = v;
     cursor[i] = v;
   } else if (i == count) {
-    off[count] = tile_sum[ntiles];
+    // (first < count: the tiles before this workgroup's, its own tile's total on top)
+    uint32_t total = base;
+    if (first < count)
+      for (uint32_t t = before; t < ntiles; t++) total += tile_sum[t];
+    off[count] = total;
   }
 }
 
@@ -1264,6 +1263,8 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
   const size_t o_coff = o;   o += align((size_t)(nbins + 1) * 4);
   constexpr uint32_t HEAVY_GRID = 256;
   const size_t o_done = o;   o += align(HEAVY_GRID * 4);  // k_heavy: slices finished, per heavy bucket
+  using PtMem = typename MsmOps<F>::PtMem;
+  const size_t o_bsum = o;   o += align((size_t)sh.nb * sizeof(PtMem));  // bucket sums (identity = zero bytes)
   // [0] identity-base flag, [2] number of heavy buckets, [3] entry count; the result block follows it directly, so
   // that flags and results go to the host in one copy
   const size_t o_err = o;    o += PINNED_POINTS;
@@ -1274,11 +1275,9 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
   // k_accumulate runs a fixed number of logical threads: one full round of the GPU at four waves per SIMD.
   constexpr bool is_g2 = sizeof(F) > sizeof(Fq);
   const uint32_t lanes = (uint32_t)ctx->cu_count * 4 * 64 * 4 / MsmOps<F>::LP;
-  using PtMem = typename MsmOps<F>::PtMem;
   const size_t o_pts1 = o;   o += align(2 * (size_t)lanes * sizeof(PtMem));
   const size_t o_heavy = o;  o += align((size_t)sh.nb * 4);
   const size_t o_slice = o;  o += align(HEAVY_GRID * sizeof(PtMem));
-  const size_t o_bsum = o;   o += align((size_t)sh.nb * sizeof(PtMem));
   const size_t o_mid = o;    o += align((size_t)nsets * fold.mid() * sizeof(PtMem));
   const uint32_t ntiles = (ncount + SCAN_TILE - 1) / SCAN_TILE;
   constexpr uint32_t LP = MsmOps<F>::LP;
@@ -1318,8 +1317,7 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
   uint32_t* wg_tiles_sum = (uint32_t*)(base + o_wgt);
   PtMem* ones_part = (PtMem*)(base + o_part);
 
-  ZG_HIP(ctx, hipMemsetAsync(base, 0, o_zero_end, st));  // every counter and flag
-  ZG_HIP(ctx, hipMemsetAsync(bsum, 0, (size_t)sh.nb * sizeof(PtMem), st));
+  ZG_HIP(ctx, hipMemsetAsync(base, 0, o_zero_end, st));  // every counter and flag, and the bucket sums
   // whose sorted entries the kernels below walk: this launch's, or one group's part of the lender's
   const uint2* walk_rec = rec;
   const uint32_t* walk_off = off;        // offsets of the nb digit buckets (and the end of the last one)
@@ -1338,13 +1336,10 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
     k_sort_count<F><<<sgrid, 256, 0, st>>>(jt, sh, ss, wg_hist);
     // exclusive scan of the (bin, workgroup) histogram, in place: every workgroup's run start in every bin
     k_scan_local<<<wg_tiles, 256, 0, st>>>(wg_hist, (uint32_t)n_wgh, wg_hist, wg_tiles_sum);
-    k_scan_tiles<<<1, 1024, 0, st>>>(wg_tiles_sum, wg_tiles);
     k_scan_fixup<<<(unsigned)((n_wgh + 1 + 255) / 256), 256, 0, st>>>(wg_hist, wg_hist, (uint32_t)n_wgh, wg_tiles_sum, wg_tiles);
-    k_coarse_offsets<<<1, 256, 0, st>>>(wg_hist, sgrid, (uint32_t)n_wgh, ss.ncoarse, sh.G, coff, hist, sh.nb);
-    k_sort_scatter<F><<<sgrid, 256, 0, st>>>(jt, sh, ss, wg_hist, rec0, rec);
+    k_sort_scatter<F><<<sgrid, 256, 0, st>>>(jt, sh, ss, wg_hist, (uint32_t)n_wgh, rec0, rec, coff, hist);
     k_fine_count<<<fgrid, 256, 0, st>>>(rec0, coff, ss, hist);
     k_scan_local<<<ntiles, 256, 0, st>>>(hist, ncount, off, tiles);
-    k_scan_tiles<<<1, 1024, 0, st>>>(tiles, ntiles);
     k_scan_fixup<<<(ncount + 1 + 255) / 256, 256, 0, st>>>(off, cursor, ncount, tiles, ntiles);
     k_fine_scatter<<<fgrid, 256, 0, st>>>(rec0, coff, ss, cursor, rec);
   }
