@@ -313,6 +313,9 @@ struct ChunkLayout {
   size_t stride;
 };
 zg16_status hshard_tables(zg16_ctx* ctx, unsigned log_m, unsigned log_g, unsigned shard, const HShardTables** out);
+zg16_status hshard_local_ntt_batch(zg16_ctx* ctx, unsigned log_l, const HShardTables* t, int nvec, const Fr* const* src,
+                                   Fr* const* dst, bool inverse, const int* which, const Fr* const* subvec,
+                                   const ChunkLayout* src_chunks, const ChunkLayout* dst_chunks);
 zg16_status hshard_local_ntt(zg16_ctx* ctx, unsigned log_l, const HShardTables* t, const Fr* src, Fr* dst, bool inverse,
                              int which, const Fr* subvec, const ChunkLayout* src_chunks = nullptr,
                              const ChunkLayout* dst_chunks = nullptr);
@@ -323,6 +326,7 @@ zg16_status pow_table_device(zg16_ctx* ctx, Fr* out, size_t count, const Fr& bas
 // this shard's 2^(log_n - log_g) elements.
 zg16_status ntt_cross_device(zg16_ctx* ctx, Fr* data, unsigned log_n, unsigned log_g, unsigned shard, bool inverse);
 zg16_status ntt_cross_chunked(zg16_ctx* ctx, const Fr* in, size_t in_stride, Fr* out, size_t out_stride, unsigned log_n,
-                              unsigned log_g, unsigned shard, bool inverse, const Fr* mulvec);
+                              unsigned log_g, unsigned shard, bool inverse, const Fr* mulvec, int nvec = 1,
+                              size_t in_vstride = 0, size_t out_vstride = 0);
 
 }  // namespace zg

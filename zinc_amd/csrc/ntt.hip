@@ -11,6 +11,8 @@
 // pass C transforms over i3 (contiguous) for a tile of adjacent k1 and scatters to natural order.
 // Each workgroup stages a T x R tile (T*R <= 1024 elements, 32 KiB) in LDS and runs the R-point
 // transforms there, so every pass is one read and one write of the array.
+#include <memory>
+
 #include "common.hpp"
 #include "fp29.hpp"
 
@@ -145,10 +147,20 @@ struct PassExtras {
   uint32_t factor_const;
 };
 
-__global__ __launch_bounds__(256, 4) void k_ntt_pass(const Fr* __restrict__ in, Fr* __restrict__ out,
-                                                     PassParams p, const Fr29* __restrict__ w_small,
-                                                     PassExtras ex) {
+// Up to three vectors of one size go through the same pass in one launch (blockIdx.y picks the vector): below 2^20
+// elements a pass has fewer workgroups than the GPU has slots, and the a, b, c transforms of a proof are independent.
+static constexpr int PASS_BATCH = 3;
+struct PassBatch {
+  const Fr* in[PASS_BATCH];
+  Fr* out[PASS_BATCH];
+  PassExtras ex[PASS_BATCH];
+};
+
+__global__ __launch_bounds__(256, 4) void k_ntt_pass(PassBatch pb, PassParams p, const Fr29* __restrict__ w_small) {
   __shared__ uint32_t s[TILE_ELEMS * 9];
+  const Fr* in = pb.in[blockIdx.y];
+  Fr* out = pb.out[blockIdx.y];
+  const PassExtras ex = pb.ex[blockIdx.y];
   const uint32_t tid = threadIdx.x;
   const uint32_t logR = p.logR, logT = p.logT;
   const uint32_t R = 1u << logR, T = 1u << logT, E = R << logT;
@@ -571,19 +583,18 @@ void ntt_free_domains(zg16_ctx* ctx) {
 // Unnormalised transform: dst[i] = DFT_{w^+-1}(src)[i] * (post_scale ? post_scale[i] : 1).  dst may
 // alias src.  The factor rides on the last pass's store, so `ifft` followed by a coset scaling (or
 // `icoset_fft`'s trailing g^-i / m) costs no extra product and no extra pass.
-static zg16_status ntt_raw(zg16_ctx* ctx, NttDomain* d, const Fr* src, Fr* dst, bool inverse,
-                           const Fr29* post_scale = nullptr, const PassExtras* last = nullptr,
-                           const ChunkLayout* src_chunks = nullptr, const ChunkLayout* dst_chunks = nullptr) {
+// nvec (at most PASS_BATCH) transforms of the domain's size, every pass one launch over all of them: vector v goes
+// from src[v] to dst[v] (in place allowed) and takes last[v] on its last store.  split_last: the last pass is
+// launched vector by vector, in order (a vector's last store may then read an earlier vector's result: mulvec).
+static zg16_status ntt_raw_batch(zg16_ctx* ctx, NttDomain* d, int nvec, const Fr* const* src, Fr* const* dst, bool inverse,
+                                 const PassExtras* last, const ChunkLayout* src_chunks = nullptr,
+                                 const ChunkLayout* dst_chunks = nullptr, bool split_last = false) {
   const unsigned n = d->log_n;
-  if (n == 0) {
-    if (dst != src) ZG_HIP(ctx, hipMemcpyAsync(dst, src, sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
-    if (post_scale) k_scale_const<<<1, 256, 0, ctx->stream>>>(dst, 1, d->minv);  // g^0 / m
-    return ZG16_OK;
-  }
+  if (nvec < 1 || nvec > PASS_BATCH || n == 0) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "bad transform batch");
   const NttPlan& pl = d->plan;
   const int dir = inverse ? 1 : 0;
   Fr* tmp = nullptr;
-  if (pl.r1) ZG_TRY(scratch_get(ctx, 0, sizeof(Fr) << n, (void**)&tmp));
+  if (pl.r1) ZG_TRY(scratch_get(ctx, 0, (size_t)nvec * (sizeof(Fr) << n), (void**)&tmp));
   hipStream_t st = ctx->stream;
   const double bytes = 64.0 * (double)((size_t)1 << n);
   // a chunked source is read by the first pass, a chunked destination written by the last
@@ -597,21 +608,46 @@ static zg16_status ntt_raw(zg16_ctx* ctx, NttDomain* d, const Fr* src, Fr* dst, 
     last_pass.out_rlog = dst_chunks->log_blk;
     last_pass.out_rstride = (uint32_t)dst_chunks->stride;
   }
+  PassBatch pa = {}, pbb = {}, pc = {};
+  for (int v = 0; v < nvec; v++) {
+    Fr* t = tmp ? tmp + ((size_t)v << n) : nullptr;
+    pa.in[v] = src[v]; pa.out[v] = t; pa.ex[v] = PassExtras{d->tw_a[dir], nullptr, nullptr, 0};
+    pbb.in[v] = t; pbb.out[v] = t; pbb.ex[v] = PassExtras{d->tw_b[dir], nullptr, nullptr, 0};
+    pc.in[v] = pl.r1 ? t : src[v]; pc.out[v] = dst[v]; pc.ex[v] = last[v];
+  }
   if (pl.r1) {
-    KernelTimer kt(ctx, K_NTT_PASS, bytes);
-    k_ntt_pass<<<pl.grid_a, 256, 0, st>>>(src, tmp, first, d->w_small[dir], PassExtras{d->tw_a[dir], nullptr, nullptr, 0});
+    KernelTimer kt(ctx, K_NTT_PASS, nvec * bytes);
+    k_ntt_pass<<<dim3(pl.grid_a, nvec), 256, 0, st>>>(pa, first, d->w_small[dir]);
   }
   if (pl.r2) {
-    KernelTimer kt(ctx, K_NTT_PASS, bytes);
-    k_ntt_pass<<<pl.grid_b, 256, 0, st>>>(tmp, tmp, pl.b, d->w_small[dir], PassExtras{d->tw_b[dir], nullptr, nullptr, 0});
+    KernelTimer kt(ctx, K_NTT_PASS, nvec * bytes);
+    k_ntt_pass<<<dim3(pl.grid_b, nvec), 256, 0, st>>>(pbb, pl.b, d->w_small[dir]);
   }
-  {
-    KernelTimer kt(ctx, K_NTT_PASS, bytes);
-    k_ntt_pass<<<pl.grid_c, 256, 0, st>>>(pl.r1 ? tmp : src, dst, last_pass, d->w_small[dir],
-                                          last ? *last : PassExtras{post_scale, nullptr, nullptr, 0});
+  if (split_last && nvec > 1) {
+    for (int v = 0; v < nvec; v++) {
+      PassBatch one = {};
+      one.in[0] = pc.in[v]; one.out[0] = pc.out[v]; one.ex[0] = pc.ex[v];
+      KernelTimer kt(ctx, K_NTT_PASS, bytes);
+      k_ntt_pass<<<dim3(pl.grid_c, 1), 256, 0, st>>>(one, last_pass, d->w_small[dir]);
+    }
+  } else {
+    KernelTimer kt(ctx, K_NTT_PASS, nvec * bytes);
+    k_ntt_pass<<<dim3(pl.grid_c, nvec), 256, 0, st>>>(pc, last_pass, d->w_small[dir]);
   }
   ZG_HIP(ctx, hipGetLastError());
   return ZG16_OK;
+}
+
+static zg16_status ntt_raw(zg16_ctx* ctx, NttDomain* d, const Fr* src, Fr* dst, bool inverse,
+                           const Fr29* post_scale = nullptr, const PassExtras* last = nullptr,
+                           const ChunkLayout* src_chunks = nullptr, const ChunkLayout* dst_chunks = nullptr) {
+  if (d->log_n == 0) {
+    if (dst != src) ZG_HIP(ctx, hipMemcpyAsync(dst, src, sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
+    if (post_scale) k_scale_const<<<1, 256, 0, ctx->stream>>>(dst, 1, d->minv);  // g^0 / m
+    return ZG16_OK;
+  }
+  const PassExtras ex = last ? *last : PassExtras{post_scale, nullptr, nullptr, 0};
+  return ntt_raw_batch(ctx, d, 1, &src, &dst, inverse, &ex, src_chunks, dst_chunks);
 }
 
 static unsigned ew_grid(size_t n) {
@@ -691,8 +727,22 @@ zg16_status h_pipeline_device(zg16_ctx* ctx, Fr* a, Fr* b, Fr* c, unsigned log_m
     ZG_HIP(ctx, hipGetLastError());
     return ZG16_OK;
   }
-  // c <- ifft(c) / Z
   const PassExtras scale_c = {d->kz, nullptr, nullptr, 1};
+  // Below 2^20 rows a pass has fewer workgroups than the GPU has room for (and a proof is a chain of launches): the
+  // three inverse transforms go through their passes together, so do the first passes of a's and b's forward
+  // transforms (b's last store reads a's result).  Seven launches instead of twelve.  ZG16_NTT_BATCH=0: one by one.
+  static const bool batch_wanted = !(getenv("ZG16_NTT_BATCH") && atoi(getenv("ZG16_NTT_BATCH")) == 0);
+  if (batch_wanted && d->plan.r1 && d->plan.grid_c < 1024) {
+    const Fr* src3[3] = {c, a, b};
+    Fr* dst3[3] = {c, a, b};
+    const PassExtras inv3[3] = {scale_c, {d->gm, nullptr, nullptr, 0}, {d->gm, nullptr, nullptr, 0}};
+    ZG_TRY(ntt_raw_batch(ctx, d, 3, src3, dst3, true, inv3));
+    const PassExtras fwd2[2] = {{nullptr, nullptr, nullptr, 0}, {nullptr, a, nullptr, 0}};
+    ZG_TRY(ntt_raw_batch(ctx, d, 2, src3 + 1, dst3 + 1, false, fwd2, nullptr, nullptr, true));
+    const PassExtras finish = {d->hz, nullptr, c, 0};
+    return ntt_raw(ctx, d, b, a, true, nullptr, &finish);
+  }
+  // c <- ifft(c) / Z
   ZG_TRY(ntt_raw(ctx, d, c, c, true, nullptr, &scale_c));
   ZG_TRY(coset_evals_device(ctx, a, log_m));
   ZG_TRY(ntt_raw(ctx, d, b, b, true, d->gm));
@@ -786,6 +836,24 @@ zg16_status hshard_local_ntt(zg16_ctx* ctx, unsigned log_l, const HShardTables* 
   return ntt_raw(ctx, d, src, dst, inverse, nullptr, &ex, src_chunks, dst_chunks);
 }
 
+// nvec (at most 3) of those transforms with every pass one launch over all of them; the vectors share the direction
+// and the layouts, which[v] and subvec[v] are per vector.
+zg16_status hshard_local_ntt_batch(zg16_ctx* ctx, unsigned log_l, const HShardTables* t, int nvec, const Fr* const* src,
+                                   Fr* const* dst, bool inverse, const int* which, const Fr* const* subvec,
+                                   const ChunkLayout* src_chunks, const ChunkLayout* dst_chunks) {
+  NttDomain* d;
+  ZG_TRY(get_domain(ctx, log_l, &d));
+  if (log_l == 0 || nvec < 1 || nvec > PASS_BATCH) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "bad sharded transform batch");
+  PassExtras ex[PASS_BATCH];
+  for (int v = 0; v < nvec; v++) {
+    ex[v] = PassExtras{nullptr, nullptr, nullptr, 0};
+    if (which[v] == 1) ex[v].factor = t->gm;
+    if (which[v] == 2) { ex[v].factor = t->kz; ex[v].factor_const = 1; }
+    if (which[v] == 3) { ex[v].factor = t->hz; ex[v].subvec = subvec ? subvec[v] : nullptr; }
+  }
+  return ntt_raw_batch(ctx, d, nvec, src, dst, inverse, ex, src_chunks, dst_chunks);
+}
+
 __global__ __launch_bounds__(256) void k_mul_vec(Fr* a, const Fr* __restrict__ b, uint32_t n) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) a[i] = mul(a[i], b[i]);
 }
@@ -815,10 +883,12 @@ struct CrossRoots {
 template <int LG>
 __global__ __launch_bounds__(256) void k_ntt_cross(const Fr* in, size_t in_stride, Fr* out, size_t out_stride, uint32_t blk,
                                                    const Fr* __restrict__ tw, CrossRoots roots, Fr scale0, int inverse,
-                                                   const Fr* __restrict__ mulvec) {
+                                                   const Fr* __restrict__ mulvec, size_t in_vstride, size_t out_vstride) {
   constexpr int G = 1 << LG;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= blk) return;
+  in += blockIdx.y * in_vstride;    // vector blockIdx.y of a launch over several vectors
+  out += blockIdx.y * out_vstride;
   Fr y[G];
 #pragma unroll
   for (int g = 0; g < G; g++) {
@@ -848,8 +918,18 @@ __global__ __launch_bounds__(256) void k_ntt_cross(const Fr* in, size_t in_strid
 
 // The twiddle table of one (size, shard count, shard, direction): [G - 1][L / G] entries
 // w_N^(+-g k2) for k2 in this shard's slice, times 1/G when inverse.  Built on first use and kept.
+struct CrossTable {
+  Fr* tw = nullptr;
+  CrossRoots roots;
+  Fr scale0;
+};
+
 void ntt_free_cross_tables(zg16_ctx* ctx) {
-  for (auto& kv : ctx->cross_tables) (void)hipFree(kv.second);
+  for (auto& kv : ctx->cross_tables) {
+    CrossTable* t = (CrossTable*)kv.second;
+    (void)hipFree(t->tw);
+    delete t;
+  }
   ctx->cross_tables.clear();
 }
 
@@ -858,49 +938,56 @@ zg16_status ntt_cross_device(zg16_ctx* ctx, Fr* data, unsigned log_n, unsigned l
 }
 
 // The same with the blocks of the input and of the output `in_stride` / `out_stride` elements apart (0: contiguous)
-// and, for a forward step, an element-wise product with `mulvec` riding on the store.
+// and, for a forward step, an element-wise product with `mulvec` riding on the store.  nvec > 1: that many vectors in
+// one launch, vector v at in + v in_vstride / out + v out_vstride (no mulvec then).
 zg16_status ntt_cross_chunked(zg16_ctx* ctx, const Fr* in, size_t in_stride, Fr* out, size_t out_stride, unsigned log_n,
-                              unsigned log_g, unsigned shard, bool inverse, const Fr* mulvec) {
+                              unsigned log_g, unsigned shard, bool inverse, const Fr* mulvec, int nvec, size_t in_vstride,
+                              size_t out_vstride) {
   const uint32_t G = 1u << log_g, blk = 1u << (log_n - 2 * log_g);
+  if (nvec < 1 || (nvec > 1 && mulvec)) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "bad cross-step batch");
   if (log_g == 0) {
-    if (in != out) ZG_HIP(ctx, hipMemcpyAsync(out, in, (sizeof(Fr) << log_n), hipMemcpyDeviceToDevice, ctx->stream));
+    for (int v = 0; v < nvec; v++)
+      if (in != out) ZG_HIP(ctx, hipMemcpyAsync(out + v * out_vstride, in + v * in_vstride, (sizeof(Fr) << log_n), hipMemcpyDeviceToDevice, ctx->stream));
     return ZG16_OK;
   }
   if (!in_stride) in_stride = blk;
   if (!out_stride) out_stride = blk;
-  Fr omega = host_root_of_unity();
-  for (unsigned i = log_n; i < 28; i++) omega = sqr(omega);
-  if (inverse) omega = inv(omega);
-  const Fr g_inv = inv(from_u64<FrParams>(G));
   const uint64_t key = ((uint64_t)log_n << 32) | (log_g << 16) | (shard << 1) | (inverse ? 1 : 0);
   hipStream_t st = ctx->stream;
-  Fr* tw;
+  CrossTable* t;
   auto it = ctx->cross_tables.find(key);
   if (it != ctx->cross_tables.end()) {
-    tw = (Fr*)it->second;
+    t = (CrossTable*)it->second;
   } else {
-    ZG_HIP(ctx, hipMalloc((void**)&tw, (size_t)(G - 1) * blk * sizeof(Fr)));
+    // (the roots are host field arithmetic -- an inversion among it -- and are kept with the table: a proof calls
+    // this six times)
+    Fr omega = host_root_of_unity();
+    for (unsigned i = log_n; i < 28; i++) omega = sqr(omega);
+    if (inverse) omega = inv(omega);
+    const Fr g_inv = inv(from_u64<FrParams>(G));
+    std::unique_ptr<CrossTable> fresh(new CrossTable());
+    ZG_HIP(ctx, hipMalloc((void**)&fresh->tw, (size_t)(G - 1) * blk * sizeof(Fr)));
     for (uint32_t g = 1; g < G; g++) {
       const Fr base = pow_u64(omega, g);
       Fr c = pow_u64(base, (uint64_t)shard * blk);
       if (inverse) c = mul(c, g_inv);
-      k_pow_table<<<(blk + 4095) / 4096, 256, 0, st>>>(tw + (size_t)(g - 1) * blk, blk, base, c);
+      k_pow_table<<<(blk + 4095) / 4096, 256, 0, st>>>(fresh->tw + (size_t)(g - 1) * blk, blk, base, c);
     }
-    ctx->cross_tables[key] = tw;
+    const Fr wg = pow_u64(omega, (uint64_t)1 << (log_n - log_g));  // w_G (or its inverse)
+    Fr p = Fr::one();
+    for (uint32_t j = 0; j < 4; j++) {
+      fresh->roots.w[j] = p;
+      p = mul(p, wg);
+    }
+    fresh->scale0 = inverse ? g_inv : Fr::one();
+    t = fresh.release();
+    ctx->cross_tables[key] = t;
   }
-  CrossRoots roots;
-  const Fr wg = pow_u64(omega, (uint64_t)1 << (log_n - log_g));  // w_G (or its inverse)
-  Fr p = Fr::one();
-  for (uint32_t j = 0; j < 4; j++) {
-    roots.w[j] = p;
-    p = mul(p, wg);
-  }
-  const Fr scale0 = inverse ? g_inv : Fr::one();
-  const unsigned grid = (blk + 255) / 256;
+  const dim3 grid((blk + 255) / 256, (unsigned)nvec);
   switch (log_g) {
-    case 1: k_ntt_cross<1><<<grid, 256, 0, st>>>(in, in_stride, out, out_stride, blk, tw, roots, scale0, inverse, mulvec); break;
-    case 2: k_ntt_cross<2><<<grid, 256, 0, st>>>(in, in_stride, out, out_stride, blk, tw, roots, scale0, inverse, mulvec); break;
-    default: k_ntt_cross<3><<<grid, 256, 0, st>>>(in, in_stride, out, out_stride, blk, tw, roots, scale0, inverse, mulvec); break;
+    case 1: k_ntt_cross<1><<<grid, 256, 0, st>>>(in, in_stride, out, out_stride, blk, t->tw, t->roots, t->scale0, inverse, mulvec, in_vstride, out_vstride); break;
+    case 2: k_ntt_cross<2><<<grid, 256, 0, st>>>(in, in_stride, out, out_stride, blk, t->tw, t->roots, t->scale0, inverse, mulvec, in_vstride, out_vstride); break;
+    default: k_ntt_cross<3><<<grid, 256, 0, st>>>(in, in_stride, out, out_stride, blk, t->tw, t->roots, t->scale0, inverse, mulvec, in_vstride, out_vstride); break;
   }
   ZG_HIP(ctx, hipGetLastError());
   return ZG16_OK;

@@ -175,8 +175,7 @@ zg16_status zg16_hshard_stage(zg16_hshard* hs, int stage, const uint64_t* z_in, 
     ZG_HIP(ctx, hipEventRecord(hs->ev_z, st));
     // rows first: the transforms are the critical path; the witness multiexps fill the GPU beside them
     ZG_TRY(spmv_blocks_device(ctx, r, z, tmp, tmp + L, tmp + 2 * L, log_blk, (uint32_t)L, hs->shard << log_blk, (uint32_t)L));
-    for (int v = 0; v < 3; v++)
-      ZG_TRY(ntt_cross_chunked(ctx, tmp + v * L, 0, work + v * blk, 3 * blk, hs->log_m, hs->log_g, hs->shard, true, nullptr));
+    ZG_TRY(ntt_cross_chunked(ctx, tmp, 0, work, 3 * blk, hs->log_m, hs->log_g, hs->shard, true, nullptr, 3, L, blk));
     if (hs->helper.joinable()) hs->helper.join();  // (a proof that was abandoned part-way)
     hs->helper_status = ZG16_OK;
     if (hs->stream_ordered && !ctx->profile && hs->proofs > 0) {
@@ -190,11 +189,16 @@ zg16_status zg16_hshard_stage(zg16_hshard* hs, int stage, const uint64_t* z_in, 
   } else if (stage == 1) {
     // what arrived: block g of vector v at (3 g + v) blk; what leaves: block h of vector v at (2 h + v) blk
     const ChunkLayout in3 = {log_blk, 3 * blk}, out2 = {log_blk, 2 * blk};
-    ZG_TRY(hshard_local_ntt(ctx, hs->log_l, hs->tables, got + 2 * blk, hs->c_coef, true, 2, nullptr, &in3, nullptr));
-    for (int v = 0; v < 2; v++) {
-      ZG_TRY(hshard_local_ntt(ctx, hs->log_l, hs->tables, got + v * blk, tmp + v * L, true, 1, nullptr, &in3, nullptr));
-      ZG_TRY(hshard_local_ntt(ctx, hs->log_l, hs->tables, tmp + v * L, work + v * blk, false, 0, nullptr, nullptr, &out2));
-    }
+    // the three inverse transforms go through their passes together, then the two forward ones: four launches (a
+    // pass over 2^17 elements is 128 workgroups)
+    const Fr* in3v[3] = {got + 2 * blk, got, got + blk};
+    Fr* out3v[3] = {hs->c_coef, tmp, tmp + L};
+    const int which3[3] = {2, 1, 1};
+    ZG_TRY(hshard_local_ntt_batch(ctx, hs->log_l, hs->tables, 3, in3v, out3v, true, which3, nullptr, &in3, nullptr));
+    const Fr* in2v[2] = {tmp, tmp + L};
+    Fr* out2v[2] = {work, work + blk};
+    const int which2[2] = {0, 0};
+    ZG_TRY(hshard_local_ntt_batch(ctx, hs->log_l, hs->tables, 2, in2v, out2v, false, which2, nullptr, nullptr, &out2));
     n_ex = 2;
   } else if (stage == 2) {
     // the coset evaluations of a, then those of b times a's as they are stored, then the inverse cross step
