@@ -325,6 +325,8 @@ zg16_status pow_table_device(zg16_ctx* ctx, Fr* out, size_t count, const Fr& bas
 // The cross-GPU step of a 2^log_n-point transform sharded over 2^log_g GPUs (see ntt.hip), in place on
 // this shard's 2^(log_n - log_g) elements.
 zg16_status ntt_cross_device(zg16_ctx* ctx, Fr* data, unsigned log_n, unsigned log_g, unsigned shard, bool inverse);
+zg16_status ntt_cross_product(zg16_ctx* ctx, const Fr* a, const Fr* b, size_t in_stride, Fr* out, size_t out_stride,
+                              unsigned log_n, unsigned log_g, unsigned shard);
 zg16_status ntt_cross_chunked(zg16_ctx* ctx, const Fr* in, size_t in_stride, Fr* out, size_t out_stride, unsigned log_n,
                               unsigned log_g, unsigned shard, bool inverse, const Fr* mulvec, int nvec = 1,
                               size_t in_vstride = 0, size_t out_vstride = 0);

@@ -878,6 +878,23 @@ struct CrossRoots {
   Fr w[4];  // w_G^j (or its inverse), j < G/2
 };
 
+// The G-point transform across the blocks, in registers: y in bit-reversed order in, natural order out.
+template <int LG>
+ZG_D void cross_stages(Fr (&y)[1 << LG], const CrossRoots& roots) {
+  constexpr int G = 1 << LG;
+#pragma unroll
+  for (int s = 0; s < LG; s++) {
+    const int h = 1 << s;
+#pragma unroll
+    for (int u = 0; u < G / 2; u++) {
+      const int pos = u & (h - 1), i0 = ((u >> s) << (s + 1)) + pos;
+      const Fr t = pos ? mul(y[i0 + h], roots.w[pos << (LG - 1 - s)]) : y[i0 + h];
+      y[i0 + h] = sub(y[i0], t);
+      y[i0] = add(y[i0], t);
+    }
+  }
+}
+
 // in / out: block g of the vector at g * in_stride / g * out_stride elements (blk when contiguous; in may be out).
 // mulvec (forward only): the result is multiplied element-wise by the natural-order vector mulvec (block g at g blk).
 template <int LG>
@@ -896,17 +913,7 @@ __global__ __launch_bounds__(256) void k_ntt_cross(const Fr* in, size_t in_strid
     if (!inverse && g) x = mul(x, tw[(size_t)(g - 1) * blk + i]);
     y[__brev((unsigned)g) >> (32 - LG)] = x;
   }
-#pragma unroll
-  for (int s = 0; s < LG; s++) {
-    const int h = 1 << s;
-#pragma unroll
-    for (int u = 0; u < G / 2; u++) {
-      const int pos = u & (h - 1), i0 = ((u >> s) << (s + 1)) + pos;
-      const Fr t = pos ? mul(y[i0 + h], roots.w[pos << (LG - 1 - s)]) : y[i0 + h];
-      y[i0 + h] = sub(y[i0], t);
-      y[i0] = add(y[i0], t);
-    }
-  }
+  cross_stages<LG>(y, roots);
 #pragma unroll
   for (int g = 0; g < G; g++) {
     Fr x = y[g];
@@ -918,6 +925,39 @@ __global__ __launch_bounds__(256) void k_ntt_cross(const Fr* in, size_t in_strid
 
 // The twiddle table of one (size, shard count, shard, direction): [G - 1][L / G] entries
 // w_N^(+-g k2) for k2 in this shard's slice, times 1/G when inverse.  Built on first use and kept.
+// The middle of a sharded H computation in one launch: forward cross step of a and of b, their element-wise product,
+// inverse cross step of the product.  All three touch, for a given i, only the elements i of the G blocks, so a
+// thread carries its 2 G elements through in registers (three launches and two trips through memory before).
+template <int LG>
+__global__ __launch_bounds__(256) void k_ntt_cross_product(const Fr* __restrict__ a, const Fr* __restrict__ b, size_t in_stride,
+                                                           Fr* __restrict__ out, size_t out_stride, uint32_t blk,
+                                                           const Fr* __restrict__ tw_f, CrossRoots roots_f,
+                                                           const Fr* __restrict__ tw_i, CrossRoots roots_i, Fr scale0_i) {
+  constexpr int G = 1 << LG;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= blk) return;
+  Fr ya[G], yb[G];
+#pragma unroll
+  for (int g = 0; g < G; g++) {
+    Fr xa = a[(size_t)g * in_stride + i], xb = b[(size_t)g * in_stride + i];
+    if (g) {
+      const Fr t = tw_f[(size_t)(g - 1) * blk + i];
+      xa = mul(xa, t);
+      xb = mul(xb, t);
+    }
+    ya[__brev((unsigned)g) >> (32 - LG)] = xa;
+    yb[__brev((unsigned)g) >> (32 - LG)] = xb;
+  }
+  cross_stages<LG>(ya, roots_f);
+  cross_stages<LG>(yb, roots_f);
+  Fr z[G];
+#pragma unroll
+  for (int k = 0; k < G; k++) z[__brev((unsigned)k) >> (32 - LG)] = mul(ya[k], yb[k]);
+  cross_stages<LG>(z, roots_i);
+#pragma unroll
+  for (int g = 0; g < G; g++) out[(size_t)g * out_stride + i] = mul(z[g], g ? tw_i[(size_t)(g - 1) * blk + i] : scale0_i);
+}
+
 struct CrossTable {
   Fr* tw = nullptr;
   CrossRoots roots;
@@ -933,25 +973,9 @@ void ntt_free_cross_tables(zg16_ctx* ctx) {
   ctx->cross_tables.clear();
 }
 
-zg16_status ntt_cross_device(zg16_ctx* ctx, Fr* data, unsigned log_n, unsigned log_g, unsigned shard, bool inverse) {
-  return ntt_cross_chunked(ctx, data, 0, data, 0, log_n, log_g, shard, inverse, nullptr);
-}
-
-// The same with the blocks of the input and of the output `in_stride` / `out_stride` elements apart (0: contiguous)
-// and, for a forward step, an element-wise product with `mulvec` riding on the store.  nvec > 1: that many vectors in
-// one launch, vector v at in + v in_vstride / out + v out_vstride (no mulvec then).
-zg16_status ntt_cross_chunked(zg16_ctx* ctx, const Fr* in, size_t in_stride, Fr* out, size_t out_stride, unsigned log_n,
-                              unsigned log_g, unsigned shard, bool inverse, const Fr* mulvec, int nvec, size_t in_vstride,
-                              size_t out_vstride) {
+// The twiddles and roots of one (size, shard count, shard, direction), built on first use and kept.
+static zg16_status cross_table(zg16_ctx* ctx, unsigned log_n, unsigned log_g, unsigned shard, bool inverse, CrossTable** out) {
   const uint32_t G = 1u << log_g, blk = 1u << (log_n - 2 * log_g);
-  if (nvec < 1 || (nvec > 1 && mulvec)) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "bad cross-step batch");
-  if (log_g == 0) {
-    for (int v = 0; v < nvec; v++)
-      if (in != out) ZG_HIP(ctx, hipMemcpyAsync(out + v * out_vstride, in + v * in_vstride, (sizeof(Fr) << log_n), hipMemcpyDeviceToDevice, ctx->stream));
-    return ZG16_OK;
-  }
-  if (!in_stride) in_stride = blk;
-  if (!out_stride) out_stride = blk;
   const uint64_t key = ((uint64_t)log_n << 32) | (log_g << 16) | (shard << 1) | (inverse ? 1 : 0);
   hipStream_t st = ctx->stream;
   CrossTable* t;
@@ -983,11 +1007,58 @@ zg16_status ntt_cross_chunked(zg16_ctx* ctx, const Fr* in, size_t in_stride, Fr*
     t = fresh.release();
     ctx->cross_tables[key] = t;
   }
+  *out = t;
+  return ZG16_OK;
+}
+
+zg16_status ntt_cross_device(zg16_ctx* ctx, Fr* data, unsigned log_n, unsigned log_g, unsigned shard, bool inverse) {
+  return ntt_cross_chunked(ctx, data, 0, data, 0, log_n, log_g, shard, inverse, nullptr);
+}
+
+// The same with the blocks of the input and of the output `in_stride` / `out_stride` elements apart (0: contiguous)
+// and, for a forward step, an element-wise product with `mulvec` riding on the store.  nvec > 1: that many vectors in
+// one launch, vector v at in + v in_vstride / out + v out_vstride (no mulvec then).
+zg16_status ntt_cross_chunked(zg16_ctx* ctx, const Fr* in, size_t in_stride, Fr* out, size_t out_stride, unsigned log_n,
+                              unsigned log_g, unsigned shard, bool inverse, const Fr* mulvec, int nvec, size_t in_vstride,
+                              size_t out_vstride) {
+  const uint32_t G = 1u << log_g, blk = 1u << (log_n - 2 * log_g);
+  if (nvec < 1 || (nvec > 1 && mulvec)) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "bad cross-step batch");
+  if (log_g == 0) {
+    for (int v = 0; v < nvec; v++)
+      if (in != out) ZG_HIP(ctx, hipMemcpyAsync(out + v * out_vstride, in + v * in_vstride, (sizeof(Fr) << log_n), hipMemcpyDeviceToDevice, ctx->stream));
+    return ZG16_OK;
+  }
+  if (!in_stride) in_stride = blk;
+  if (!out_stride) out_stride = blk;
+  hipStream_t st = ctx->stream;
+  CrossTable* t;
+  ZG_TRY(cross_table(ctx, log_n, log_g, shard, inverse, &t));
   const dim3 grid((blk + 255) / 256, (unsigned)nvec);
   switch (log_g) {
     case 1: k_ntt_cross<1><<<grid, 256, 0, st>>>(in, in_stride, out, out_stride, blk, t->tw, t->roots, t->scale0, inverse, mulvec, in_vstride, out_vstride); break;
     case 2: k_ntt_cross<2><<<grid, 256, 0, st>>>(in, in_stride, out, out_stride, blk, t->tw, t->roots, t->scale0, inverse, mulvec, in_vstride, out_vstride); break;
     default: k_ntt_cross<3><<<grid, 256, 0, st>>>(in, in_stride, out, out_stride, blk, t->tw, t->roots, t->scale0, inverse, mulvec, in_vstride, out_vstride); break;
+  }
+  ZG_HIP(ctx, hipGetLastError());
+  return ZG16_OK;
+}
+
+ // (see k_ntt_cross_product) a, b: blocks in_stride apart; out: blocks out_stride apart (0: contiguous)
+zg16_status ntt_cross_product(zg16_ctx* ctx, const Fr* a, const Fr* b, size_t in_stride, Fr* out, size_t out_stride,
+                              unsigned log_n, unsigned log_g, unsigned shard) {
+  const uint32_t blk = 1u << (log_n - 2 * log_g);
+  if (log_g < 1 || log_g > 3) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "bad shard count for the fused cross step");
+  if (!in_stride) in_stride = blk;
+  if (!out_stride) out_stride = blk;
+  CrossTable *f, *v;
+  ZG_TRY(cross_table(ctx, log_n, log_g, shard, false, &f));
+  ZG_TRY(cross_table(ctx, log_n, log_g, shard, true, &v));
+  const unsigned grid = (blk + 255) / 256;
+  hipStream_t st = ctx->stream;
+  switch (log_g) {
+    case 1: k_ntt_cross_product<1><<<grid, 256, 0, st>>>(a, b, in_stride, out, out_stride, blk, f->tw, f->roots, v->tw, v->roots, v->scale0); break;
+    case 2: k_ntt_cross_product<2><<<grid, 256, 0, st>>>(a, b, in_stride, out, out_stride, blk, f->tw, f->roots, v->tw, v->roots, v->scale0); break;
+    default: k_ntt_cross_product<3><<<grid, 256, 0, st>>>(a, b, in_stride, out, out_stride, blk, f->tw, f->roots, v->tw, v->roots, v->scale0); break;
   }
   ZG_HIP(ctx, hipGetLastError());
   return ZG16_OK;

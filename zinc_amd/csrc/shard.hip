@@ -201,10 +201,8 @@ zg16_status zg16_hshard_stage(zg16_hshard* hs, int stage, const uint64_t* z_in, 
     ZG_TRY(hshard_local_ntt_batch(ctx, hs->log_l, hs->tables, 2, in2v, out2v, false, which2, nullptr, nullptr, &out2));
     n_ex = 2;
   } else if (stage == 2) {
-    // the coset evaluations of a, then those of b times a's as they are stored, then the inverse cross step
-    ZG_TRY(ntt_cross_chunked(ctx, got, 2 * blk, tmp, 0, hs->log_m, hs->log_g, hs->shard, false, nullptr));
-    ZG_TRY(ntt_cross_chunked(ctx, got + blk, 2 * blk, tmp + L, 0, hs->log_m, hs->log_g, hs->shard, false, tmp));
-    ZG_TRY(ntt_cross_chunked(ctx, tmp + L, 0, work, 0, hs->log_m, hs->log_g, hs->shard, true, nullptr));
+    // the coset evaluations of a and of b (forward cross steps), their product, the inverse cross step: one launch
+    ZG_TRY(ntt_cross_product(ctx, got, got + blk, 2 * blk, work, 0, hs->log_m, hs->log_g, hs->shard));
     n_ex = 1;
   } else {
     ZG_TRY(hshard_local_ntt(ctx, hs->log_l, hs->tables, got, hs->h, true, 3, hs->c_coef));
