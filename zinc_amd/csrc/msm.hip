@@ -512,37 +512,49 @@ __global__ __launch_bounds__(256, kMinWaves<F>) void k_accumulate(JobTable<F> jt
   if (cur != KEY_INVALID) flush();
 }
 
-// One group of SL lanes per bucket adds, in the spread form, the pieces level 0 left of a bucket it cut at chunk
-// edges.  Buckets in more than LIGHT_PIECES pieces are appended to heavy_list for k_heavy.
+// Q adjacent groups of SL lanes per bucket add, in the spread form, the pieces level 0 left of a bucket it cut at
+// chunk edges: group q takes pieces q, q + Q, ... and the groups fold by shuffles.  Q is 1 when there are buckets
+// enough to fill the GPU with one group each (a 2^20-point query: 65 536 buckets) and up to 8 for the few, deeply cut
+// buckets of a mid-sized query (8192 buckets in ~25 pieces: a chain of 25 additions became 4 + 3).  Buckets in more
+// than LIGHT_PIECES pieces are appended to heavy_list for k_heavy.  Q * SL divides 64.
 template <class F>
-__global__ __launch_bounds__(256, kMinWaves<F>) void k_combine(uint32_t nb, uint32_t lanes,
+__global__ __launch_bounds__(256, kMinWaves<F>) void k_combine(uint32_t nb, uint32_t lanes, uint32_t Q,
                                                                  const uint32_t* __restrict__ off,
                                                                  const typename MsmOps<F>::PtMem* __restrict__ pts1,
                                                                  typename MsmOps<F>::PtMem* __restrict__ bucket_sum,
                                                                  uint32_t* __restrict__ heavy_count,
                                                                  uint32_t* __restrict__ heavy_list) {
   using O = MsmOps<F>;
-  const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) / O::SL;
-  if (b >= nb) return;  // (whole groups leave)
+  const uint32_t grp = (blockIdx.x * blockDim.x + threadIdx.x) / O::SL;
+  const uint32_t b = grp / Q, q = grp % Q;
   const uint32_t e0 = off[0];  // positions below are counted from the first entry of this launch's buckets
   const uint32_t K = chunk_len(off[nb] - e0, lanes, nb);
-  const uint32_t s = off[b] - e0, e = off[b + 1] - e0;
-  if (e <= s) return;
-  const uint32_t pieces = (e - 1) / K - s / K + 1;
-  if (pieces == 1) return;  // level 0 finished the bucket inside one chunk
-  if (pieces > LIGHT_PIECES) {
-    if (threadIdx.x % O::SL == 0) heavy_list[atomicAdd(heavy_count, 1u)] = b;
-    return;
+  // (every lane of a wave stays for the shuffles below; a bucket with nothing to add here has no pieces)
+  uint32_t s = 0, pieces = 0;
+  if (b < nb) {
+    s = off[b] - e0;
+    const uint32_t e = off[b + 1] - e0;
+    if (e > s) pieces = (e - 1) / K - s / K + 1;
+    if (pieces > LIGHT_PIECES) {
+      if (q == 0 && threadIdx.x % O::SL == 0) heavy_list[atomicAdd(heavy_count, 1u)] = b;
+      pieces = 0;
+    }
+    if (pieces == 1) pieces = 0;  // level 0 finished the bucket inside one chunk
   }
   // (the next piece is on its way while the current one is added: the chain is one addition after another)
-  typename O::Own acc = O::own_load(pts1 + piece_slot(s, K, 0));
-  typename O::Own next = O::own_load(pts1 + piece_slot(s, K, 1));
-  for (uint32_t p = 1; p < pieces; p++) {
+  typename O::Own acc = O::own_inf(), next = O::own_inf();
+  if (q < pieces) next = O::own_load(pts1 + piece_slot(s, K, q));
+  for (uint32_t p = q; p < pieces; p += Q) {
     const typename O::Own cur = next;
-    if (p + 1 < pieces) next = O::own_load(pts1 + piece_slot(s, K, p + 1));
+    if (p + Q < pieces) next = O::own_load(pts1 + piece_slot(s, K, p + Q));
     O::own_add(acc, cur);
   }
-  O::own_store(bucket_sum + b, acc);
+#pragma unroll 1
+  for (uint32_t d = Q / 2; d >= 1; d >>= 1) {
+    const typename O::Own o = O::own_shfl_down(acc, (int)(d * O::SL));
+    O::own_add_if(acc, o, q < d);
+  }
+  if (pieces && q == 0) O::own_store(bucket_sum + b, acc);
 }
 
 // p * k for a small unsigned k
@@ -1382,8 +1394,11 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
   }
   {
     KernelTimer kt(ctx, is_g2 ? K_MSM_ACCN_G2 : K_MSM_ACCN_G1, (double)sh.nb, st);
-    k_combine<F><<<(unsigned)(((size_t)sh.nb * MsmOps<F>::SL + 255) / 256), 256, 0, st>>>(
-        sh.nb, lanes, walk_off, pts1, bsum, err + 2, (uint32_t*)(base + o_heavy));
+    // lane groups per bucket: as many as still fit one resident round of the GPU, at most 8 (and a wave's worth)
+    uint32_t Q = 1;
+    while (Q < 8 && 2 * Q * MsmOps<F>::SL <= 64 && (size_t)sh.nb * MsmOps<F>::SL * 2 * Q <= (size_t)lanes * LP) Q *= 2;
+    k_combine<F><<<(unsigned)(((size_t)sh.nb * Q * MsmOps<F>::SL + 255) / 256), 256, 0, st>>>(
+        sh.nb, lanes, Q, walk_off, pts1, bsum, err + 2, (uint32_t*)(base + o_heavy));
     k_heavy<F><<<HEAVY_GRID, 256, 0, st>>>(err + 2, (const uint32_t*)(base + o_heavy), walk_off, sh.nb, lanes, pts1, bsum,
                                            (PtMem*)(base + o_slice), (uint32_t*)(base + o_done));
   }
