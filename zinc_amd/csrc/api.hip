@@ -845,6 +845,7 @@ static zg16_status prove_partial_impl(zg16_ctx* ctx, const zg16_pk* pk, const zg
   }
   if (tables && early) {
     early->key_terms();  // host work while the GPU is busy
+    mark("key terms");
     // poll: the runtime's blocking wait wakes up to 0.3 ms late, which is half of a small circuit's proof
     auto spin = [&](hipEvent_t e) {
       hipError_t q;
@@ -852,11 +853,14 @@ static zg16_status prove_partial_impl(zg16_ctx* ctx, const zg16_pk* pk, const zg
       return q;
     };
     ZG_HIP(ctx, spin(ev[E_Z_END]));
+    mark("witness multiexps seen");
     ZG_TRY(msm_collect<Fq>(ctx, &pend_z, g1));
+    mark("witness sums folded");
     early->with_g1(g1[1], g1[2]);
     mark("witness-query multiexps collected");
     ZG_HIP(ctx, spin(ev[E_G2_END]));
     ZG_TRY(msm_collect<Fq2>(ctx, &pend_g2, &qb2));
+    mark("G2 sums folded");
     early->with_g2(qb2);
     early_done = true;
     mark("G2 multiexp collected");

@@ -683,10 +683,12 @@ __global__ __launch_bounds__(256, kMinWaves<F>) void k_heavy(const uint32_t* __r
 
 // Weighted bucket sums without scalar multiplications.  sum_b (b+1)*S_b over B = R*H buckets with
 // b = hi*R + lo splits into  sum_lo lo*U_lo + sum_hi (R*hi + 1)*V_hi,  U_lo = sum_hi S_b (column
-// sums), V_hi = sum_lo S_b (row sums): two plain-sum arrays of R and H points.  Applying the same
-// split to U and V leaves four arrays of at most 2^ceil((c-1)/4) points whose small weighted sums
-// the host finishes (msm_collect) -- a CPU core adds points an order of magnitude faster than one
-// wave does, and the device part is two launches of log-depth sums.
+// sums), V_hi = sum_lo S_b (row sums): two plain-sum arrays of R and H points.  The weights of U are the
+// numbers lo < R and those of V are R * hi (+ 1), so bit by bit:  sum_p 2^p T_p + sum of all buckets,  T_p = the
+// sum of the U_lo with bit p of lo set (p < log R), of the V_hi with bit p - log R of hi set (above): c - 1 plain
+// sums of R / 2 or H / 2 points each (k_bit_sums), and the host finishes with c - 1 doublings and c additions per
+// bucket set (msm_collect) -- a CPU core runs such a dependent chain an order of magnitude faster than one wave
+// does, and the device part is two launches of log-depth sums.
 //
 // k_split_sums: each workgroup produces one output point (wg_spread_sum).  Array a of set blockIdx.z holds count[a] =
 // r[a] * h[a] points at in + set*in_stride + in_off[a]; outputs are r[a] column sums (index mod r)
@@ -724,6 +726,31 @@ __global__ __launch_bounds__(256, kMinWaves<F>) void k_split_sums(const typename
     else
       O::own_store(out + dst, acc);
   }
+}
+
+// Set blockIdx.y holds U (2^lR points) then V (2^lH points) at in + set * in_stride.  Workgroup blockIdx.x = p
+// writes T_p (see above) for p < lR + lH and the sum of all of U for p = lR + lH, in the library-wide XYZZ form, at
+// out_std[set * (lR + lH + 1) + p].
+template <class F>
+__global__ __launch_bounds__(256, kMinWaves<F>) void k_bit_sums(const typename MsmOps<F>::PtMem* __restrict__ in,
+                                                                  uint32_t lR, uint32_t lH, uint32_t in_stride,
+                                                                  XYZZ<F>* __restrict__ out_std) {
+  using O = MsmOps<F>;
+  __shared__ typename O::Own fold[4][O::SL];
+  const uint32_t p = blockIdx.x, set = blockIdx.y, bits = lR + lH;
+  const typename O::PtMem* U = in + (size_t)set * in_stride;
+  typename O::Own acc;
+  if (p == bits) {
+    acc = wg_spread_sum<F>(1u << lR, [&](uint32_t k) { return O::own_load(U + k); }, fold);
+  } else {
+    const typename O::PtMem* X = p < lR ? U : U + ((size_t)1 << lR);
+    const uint32_t t = p < lR ? p : p - lR, len = p < lR ? lR : lH;
+    // the k-th index with bit t set: the bits of k above t move up by one
+    acc = wg_spread_sum<F>((1u << len) >> 1, [&](uint32_t k) {
+      return O::own_load(X + ((((k >> t) << 1) | 1u) << t | (k & ((1u << t) - 1))));
+    }, fold);
+  }
+  if (threadIdx.x < O::SL) O::own_store_std(out_std + ((size_t)set * (bits + 1) + p), acc);
 }
 
 // out_std[w] = sum of part[w][0..count), in the library-wide XYZZ form.  One workgroup per w.
@@ -1120,20 +1147,16 @@ zg16_status msm_build_direct(zg16_ctx* ctx, const Affine<F>* points, size_t n, A
 template zg16_status msm_build_direct<Fq>(zg16_ctx*, const Affine<Fq>*, size_t, Affine<Fq>**);
 template zg16_status msm_build_direct<Fq2>(zg16_ctx*, const Affine<Fq2>*, size_t, Affine<Fq2>**);
 
-// How a set of 2^bits buckets is folded on the device: R*H buckets -> U (R) and V (H), then
-// U -> r1 + h1 points and V -> r2 + h2 points, all sizes powers of two (logarithms held here).
+// How a set of 2^bits buckets is folded on the device: R*H buckets -> U (R) and V (H), both powers of two
+// (logarithms held here), then one point per bit of the bucket number and the sum of all buckets.
 struct FoldShape {
-  uint32_t lR, lH, lr1, lh1, lr2, lh2;
+  uint32_t lR, lH;
   explicit FoldShape(uint32_t bits) {
     lR = (bits + 1) / 2;
     lH = bits - lR;
-    lr1 = (lR + 1) / 2;
-    lh1 = lR - lr1;
-    lr2 = (lH + 1) / 2;
-    lh2 = lH - lr2;
   }
   uint32_t mid() const { return (1u << lR) + (1u << lH); }
-  uint32_t leaves() const { return (1u << lr1) + (1u << lh1) + (1u << lr2) + (1u << lh2); }
+  uint32_t leaves() const { return lR + lH + 1; }
 };
 
 // Result block in page-locked host memory: the launch's 256 bytes of flags ([0] identity base met, [3] entry count),
@@ -1411,18 +1434,7 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
     s1.in_stride = sh.B;
     s1.out_stride = fold.mid();
     k_split_sums<F><<<dim3(fold.mid(), 1, nsets), 256, 0, st>>>(bsum, s1, mid, nullptr);
-    SplitShape s2 = {};
-    s2.narr = 2;
-    s2.r[0] = 1u << fold.lr1;
-    s2.h[0] = 1u << fold.lh1;
-    s2.in_off[1] = 1u << fold.lR;
-    s2.r[1] = 1u << fold.lr2;
-    s2.h[1] = 1u << fold.lh2;
-    s2.out_off[1] = s2.r[0] + s2.h[0];
-    s2.in_stride = fold.mid();
-    s2.out_stride = fold.leaves();
-    const uint32_t t2 = s2.r[0] + s2.h[0] > s2.r[1] + s2.h[1] ? s2.r[0] + s2.h[0] : s2.r[1] + s2.h[1];
-    k_split_sums<F><<<dim3(t2, 2, nsets), 256, 0, st>>>(mid, s2, nullptr, wstd);
+    k_bit_sums<F><<<dim3(fold.leaves(), nsets), 256, 0, st>>>(mid, fold.lR, fold.lH, fold.mid(), wstd);
   }
   ZG_HIP(ctx, hipGetLastError());
   if (ms.side)
@@ -1438,39 +1450,16 @@ zg16_status msm_launch(zg16_ctx* ctx, const MsmStreams& ms, int scratch_slot, vo
   return ZG16_OK;
 }
 
-// sum_i i * x[i], and the plain sum when `plain` is given (host)
-template <class F>
-static XYZZ<F> index_weighted_sum(const XYZZ<F>* x, uint32_t n, XYZZ<F>* plain) {
-  XYZZ<F> run = XYZZ<F>::inf(), acc = XYZZ<F>::inf();
-  for (uint32_t i = n; i-- > 1;) {
-    add_full(run, x[i]);
-    add_full(acc, run);
-  }
-  if (plain) {
-    add_full(run, x[0]);
-    *plain = run;
-  }
-  return acc;
-}
-
-// The weighted sum of one bucket set from its folded form.  Bucket b = hi*R + lo with
-// lo = a1*r1 + b1, hi = a2*r2 + b2 has weight b + 1 = b1 + r1*a1 + R*(b2 + r2*a2) + 1; the four
-// arrays hold the sums of the buckets sharing b1, a1, b2, a2 in that order.
+// The weighted sum of one bucket set from the points k_bit_sums left: sum_p 2^p leaf[p] + leaf[bits] by Horner.
 template <class F>
 static XYZZ<F> fold_finish(const XYZZ<F>* leaf, const FoldShape& f) {
-  const XYZZ<F>* ua = leaf;
-  const XYZZ<F>* ub = ua + (1u << f.lr1);
-  const XYZZ<F>* va = ub + (1u << f.lh1);
-  const XYZZ<F>* vb = va + (1u << f.lr2);
-  XYZZ<F> all;
-  XYZZ<F> t = index_weighted_sum<F>(vb, 1u << f.lh2, nullptr);
-  for (uint32_t k = 0; k < f.lr2; k++) t = dbl(t);
-  add_full(t, index_weighted_sum<F>(va, 1u << f.lr2, &all));
-  for (uint32_t k = 0; k < f.lR - f.lr1; k++) t = dbl(t);
-  add_full(t, index_weighted_sum<F>(ub, 1u << f.lh1, nullptr));
-  for (uint32_t k = 0; k < f.lr1; k++) t = dbl(t);
-  add_full(t, index_weighted_sum<F>(ua, 1u << f.lr1, nullptr));
-  add_full(t, all);
+  const uint32_t bits = f.lR + f.lH;
+  XYZZ<F> t = XYZZ<F>::inf();
+  for (uint32_t p = bits; p-- > 0;) {
+    if (!t.is_inf()) t = dbl(t);
+    add_full(t, leaf[p]);
+  }
+  add_full(t, leaf[bits]);
   return t;
 }
 

@@ -230,20 +230,29 @@ zg16_status zg16_hshard_finish(zg16_hshard* hs, zg16_partial* out) {
   hs->next_stage = 0;
   hs->proofs++;
   if (hs->helper.joinable()) hs->helper.join();
-  // let every pipeline drain before reading (or, on an error, before the caller can reuse what the kernels touch)
-  const hipError_t e1 = hipStreamSynchronize(ctx->early_stream), e2 = hipStreamSynchronize(ctx->aux_stream),
-                   e3 = hipStreamSynchronize(ctx->stream);
+  // The witness pipelines end before the h query's does: their sums are finished on the host while the GPU still
+  // works on it.  Every pipeline has drained before this returns (on an error too: the caller may then reuse what
+  // the kernels touch).  Polled: the runtime's blocking wait can wake a fraction of a millisecond late.
+  auto drained = [](hipStream_t s) {
+    hipError_t q;
+    while ((q = hipStreamQuery(s)) == hipErrorNotReady) __builtin_ia32_pause();
+    return q;
+  };
+  G1XYZZ g1[3], h_sum;
+  G2XYZZ qb2;
+  zg16_status early_status = hs->helper_status;
+  const hipError_t e1 = drained(ctx->early_stream);
+  if (early_status == ZG16_OK && e1 == hipSuccess) early_status = msm_collect<Fq>(ctx, &hs->pend_z, g1);
+  const hipError_t e2 = drained(ctx->aux_stream);
+  if (early_status == ZG16_OK && e2 == hipSuccess) early_status = msm_collect<Fq2>(ctx, &hs->pend_g2, &qb2);
+  const hipError_t e3 = drained(ctx->stream);
   profile_collect(ctx);
   ZG_HIP(ctx, e1);
   ZG_HIP(ctx, e2);
   ZG_HIP(ctx, e3);
-  ZG_TRY(hs->helper_status);
+  ZG_TRY(early_status);
   ctx->timings = zg16_timings();
   ctx->timings.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - hs->t_begin).count();
-  G1XYZZ g1[3], h_sum;
-  G2XYZZ qb2;
-  ZG_TRY(msm_collect<Fq>(ctx, &hs->pend_z, g1));
-  ZG_TRY(msm_collect<Fq2>(ctx, &hs->pend_g2, &qb2));
   ZG_TRY(msm_collect<Fq>(ctx, &hs->pend_h, &h_sum));
   add_full(g1[0], h_sum);
   memcpy(out->hl, &g1[0], sizeof g1[0]);
