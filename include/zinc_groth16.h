@@ -296,6 +296,17 @@ zg16_status zg16_hshard_stage(zg16_hshard* hs, int stage, const uint64_t* z_in, 
                               int witness_on_device, uint64_t* work_dev, uint64_t* got_dev, int* n_exchange);
 zg16_status zg16_hshard_stream_ordered(zg16_hshard* hs, int on);
 zg16_status zg16_hshard_finish(zg16_hshard* hs, zg16_partial* out);
+/* Optional: the proof's r and s (Montgomery form, as zg16_prove takes them) before stage 0, on EVERY GPU.  The
+ * assembly of bellman_ce 0.3.0 `create_proof` is linear in the query sums -- C = [s*(alpha + r*delta) + r*beta_g1]
+ * + s*a_query + r*b_query + h + l -- so each GPU then adds s*a + r*b1 of its own sums into the `hl` of the partial
+ * zg16_hshard_finish returns (a 254-bit double scalar multiplication on the host, beside its h multiexp), and on
+ * the GPU that will put the proof together (assembles != 0) a host thread prepares alpha + r*delta, beta + s*delta
+ * and the bracket above while the stages run.  zg16_hshard_assemble on that GPU adds the partials of all GPUs to
+ * them: a few dozen additions after the gather instead of the two fixed-base and the double scalar multiplication
+ * of zg16_prove_finish.  Partials made after zg16_hshard_randomness go to zg16_hshard_assemble only
+ * (zg16_prove_finish would add s*a + r*b1 a second time); r and s hold for one proof. */
+zg16_status zg16_hshard_randomness(zg16_hshard* hs, const uint64_t r_mont[4], const uint64_t s_mont[4], int assembles);
+zg16_status zg16_hshard_assemble(zg16_hshard* hs, const zg16_partial* parts, size_t n_parts, zg16_proof* out);
 
 /* The same driven from ONE process that sees all the GPUs (what a Rust host linking this library can do without a
  * launcher): a context per listed device, a host thread per GPU during a call, peer-to-peer copies for the

@@ -30,7 +30,21 @@ def main():
     z_aux = torch.from_numpy(za.view(np.int64)).cuda()
     for _ in range(2):   # the second proof reuses every buffer and table
         proof = prover.prove(z_in.data_ptr(), z_aux.data_ptr(), 1, rs[0], rs[1])
+    # the same with plain partial sums and the whole assembly on rank 0 (zg16_prove_finish)
+    plain = prover.prove(z_in.data_ptr(), z_aux.data_ptr(), 1, rs[0], rs[1], early_randomness=False)
     if rank == 0:
+        import ctypes as C
+        from zinc_amd import lib as zlib
+        from zinc_amd.groth16 import SynthesisError
+        for name in ("a", "b", "c"):
+            assert bytes(getattr(plain, name)) == bytes(getattr(proof, name)), "the two assemblies differ in %s" % name
+        # zg16_hshard_assemble without this proof's r and s is refused
+        try:
+            zinc_amd.groth16._check(ctx.handle, ctx._lib.zg16_hshard_assemble(prover.hs, (zlib.Partial * world)(), world,
+                                                                               C.byref(zlib.Proof())))
+            raise AssertionError("zg16_hshard_assemble accepted partials without zg16_hshard_randomness")
+        except SynthesisError as e:
+            assert e.status_name == "InvalidArgument", e
         whole = params.upload(ctx)
         want = prove_recorded(ctx, whole, mat, zi, za, rs[0], rs[1])
         for name in ("a", "b", "c"):

@@ -6,7 +6,7 @@ Sharded schedule (--schedule sharded): shard 0's four zg16_hshard_stage calls, s
 exchange replaced by a device copy of the same bytes from `work` to `got` on that stream (what arrives is then not
 the other ranks' data, but it is dense field elements like theirs: the kernels' work is the same).  The time of the
 real all-to-alls is NOT in it: at 2^20 rows on 8 GPUs they move 3.5 + 2.3 + 1.2 MiB per GPU and direction.
-The gather of the 640-byte partial sums and the host assembly are not in either.
+The gather of the 640-byte partial sums is not in either; the host assembly behind it is reported separately.
 
     python tools/rank_share.py [--log-rows 20] [--schedule replicated|sharded]
 """
@@ -82,7 +82,13 @@ def sharded(args, ctx, params, mat, zi_d, za_d):
         _check(ctx.handle, L.zg16_hshard_stream_ordered(hs, 1))
         part = zlib.Partial()
 
+        from zinc_amd.fields import ints_to_mont, R_MOD
+        rs = ints_to_mont([pow(7, 123456789, R_MOD), pow(5, 987654321, R_MOD)], R_MOD)
+
         def step():
+            # every rank folds s*a + r*b1 of its sums into its partial (rank 0 would also prepare the key's terms,
+            # on a thread of its own)
+            _check(ctx.handle, L.zg16_hshard_randomness(hs, zlib.as_u64p(rs[0]), zlib.as_u64p(rs[1]), 1))
             with torch.cuda.stream(stream):
                 for k in range(4):
                     nx = C.c_int()
@@ -99,7 +105,23 @@ def sharded(args, ctx, params, mat, zi_d, za_d):
             step()
         torch.cuda.synchronize()
         ms = 1e3 * (time.perf_counter() - t0) / args.reps
-        print("ranks %d, sharded schedule: shard 0 alone %.3f ms per proof (exchanges as device copies)" % (n, ms), flush=True)
+        # what rank 0 does after the gather, on n copies of this partial (the sums are then not a proof's, the work
+        # is): zg16_hshard_assemble against zg16_prove_finish on partials made without zg16_hshard_randomness
+        parts = (zlib.Partial * n)(*([part] * n))
+        proof = zlib.Proof()
+        reps, t_new = 20, 0.0
+        for _ in range(reps):
+            step()
+            t1 = time.perf_counter()
+            _check(ctx.handle, L.zg16_hshard_assemble(hs, parts, n, C.byref(proof)))
+            t_new += time.perf_counter() - t1
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            _check(None, L.zg16_prove_finish(C.byref(view), parts, n, zlib.as_u64p(rs[0]), zlib.as_u64p(rs[1]), C.byref(proof)))
+        t_old = time.perf_counter() - t1
+        print("ranks %d, sharded schedule: shard 0 alone %.3f ms per proof (exchanges as device copies); assembly after "
+              "the gather %.0f us (zg16_hshard_assemble), %.0f us (zg16_prove_finish)"
+              % (n, ms, 1e6 * t_new / reps, 1e6 * t_old / reps), flush=True)
         L.zg16_hshard_free(hs)
         L.zg16_pk_free(key)
 

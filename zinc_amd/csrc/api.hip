@@ -560,59 +560,6 @@ zg16_status zg16_r1cs_shape(const zg16_r1cs* r, size_t* n_rows, size_t* n_inputs
 // ---------------------------------------------------------------------------------------- prove
 }  // extern "C"
 
-// Final assembly (bellman_ce 0.3.0 `create_proof`, after the multiexps) in two steps, so that the part
-// that needs only the witness-side sums can run on the host while the GPU still works on the h query:
-//   A = alpha + r*delta + a_query            B = beta + s*delta + b_query (G2)
-//   C = s*A + r*(beta_g1 + b_query_g1) + (h + l)
-// which equals upstream's rs*delta + s*alpha + r*beta + s*a_query + r*b_query + h + l term by term.
-struct Assembly {
-  G1Affine alpha1, beta1, delta1;
-  G2Affine beta2, delta2;
-  Fr rc, sc;  // canonical r, s
-  G1XYZZ A, c_part;
-  G2XYZZ B;
-  // A and B in affine form, converted as soon as they are complete (beside the h multiexp, not after it)
-  G1Affine A_affine;
-  G2Affine B_affine;
-  bool have_A = false, have_B = false;
-  const FixedBaseTable<Fq>* delta1_table = nullptr;   // optional (a key handle has them)
-  const FixedBaseTable<Fq2>* delta2_table = nullptr;
-  // needs nothing from the GPU: alpha + r*delta and beta + s*delta
-  void key_terms() {
-    A = delta1_table ? delta1_table->mul(rc.v) : scalar_mul_w4(G1XYZZ::from_affine(delta1), rc.v);
-    add_mixed(A, alpha1);
-    B = delta2_table ? delta2_table->mul(sc.v) : scalar_mul_w4(G2XYZZ::from_affine(delta2), sc.v);
-    add_mixed(B, beta2);
-  }
-  void with_g2(const G2XYZZ& qb2) {
-    add_full(B, qb2);
-    B_affine = to_affine(B);
-    have_B = true;
-  }
-  void with_g1(const G1XYZZ& qa, const G1XYZZ& qb1) {
-    add_full(A, qa);
-    G1XYZZ b1 = qb1;
-    add_mixed(b1, beta1);
-    c_part = double_scalar_mul(A, sc.v, b1, rc.v);
-    A_affine = to_affine(A);
-    have_A = true;
-  }
-  void early(const G1XYZZ& qa, const G1XYZZ& qb1, const G2XYZZ& qb2) {
-    key_terms();
-    with_g2(qb2);
-    with_g1(qa, qb1);
-  }
-  void finish(const G1XYZZ& hl, zg16_proof* out) const {
-    G1XYZZ C = c_part;
-    add_full(C, hl);
-    const G1Affine Aa = have_A ? A_affine : to_affine(A), Ca = to_affine(C);
-    const G2Affine Ba = have_B ? B_affine : to_affine(B);
-    memcpy(out->a, &Aa, 64);
-    memcpy(out->b, &Ba, 128);
-    memcpy(out->c, &Ca, 64);
-  }
-};
-
 // One GPU's share of a proof.  h_external: device array of the H coefficients (2^log_m entries) computed
 // elsewhere, or null to evaluate the rows and run the transforms here.
 // early: when given (single-GPU proof), its witness-side step runs on the host as soon as the a, b_g1
@@ -974,6 +921,35 @@ zg16_status zg16_prove_finish(const zg16_pk_view* v, const zg16_partial* parts, 
   }
   Assembly as;
   as.alpha1 = alpha1; as.beta1 = beta1; as.delta1 = delta1; as.beta2 = beta2; as.delta2 = delta2;
+  // r*delta_g1 and s*delta_g2 from fixed-base tables, as a key handle keeps them: the view has none, so the tables
+  // of the last delta seen are kept here (a prover assembles many proofs under one key; building the pair costs
+  // about as much as ten assemblies without them)
+  struct DeltaTables {
+    G1Affine d1;
+    G2Affine d2;
+    FixedBaseTable<Fq> t1;
+    FixedBaseTable<Fq2> t2;
+  };
+  static std::mutex tables_mutex;
+  static std::shared_ptr<const DeltaTables> last_tables;
+  std::shared_ptr<const DeltaTables> tables;
+  {
+    std::lock_guard<std::mutex> lock(tables_mutex);
+    if (last_tables && !memcmp(&last_tables->d1, &delta1, sizeof delta1) && !memcmp(&last_tables->d2, &delta2, sizeof delta2))
+      tables = last_tables;
+  }
+  if (!tables) {
+    auto fresh = std::make_shared<DeltaTables>();
+    fresh->d1 = delta1;
+    fresh->d2 = delta2;
+    fresh->t1.build(delta1);
+    fresh->t2.build(delta2);
+    tables = fresh;
+    std::lock_guard<std::mutex> lock(tables_mutex);
+    last_tables = tables;
+  }
+  as.delta1_table = &tables->t1;
+  as.delta2_table = &tables->t2;
   as.rc = from_mont(load_fr(r_));
   as.sc = from_mont(load_fr(s_));
   as.early(qa, qb1, qb2);

@@ -132,6 +132,68 @@ zg16_status pk_upload_impl(zg16_ctx* ctx, const zg16_pk_view* v, int shard_index
 void r1cs_destroy(zg16_r1cs* r);
 }  // namespace zg
 
+namespace zg {
+// Final assembly (bellman_ce 0.3.0 `create_proof`, after the multiexps) in two steps, so that the part
+// that needs only the witness-side sums can run on the host while the GPU still works on the h query:
+//   A = alpha + r*delta + a_query            B = beta + s*delta + b_query (G2)
+//   C = s*A + r*(beta_g1 + b_query_g1) + (h + l)
+// which equals upstream's rs*delta + s*alpha + r*beta + s*a_query + r*b_query + h + l term by term.
+struct Assembly {
+  G1Affine alpha1, beta1, delta1;
+  G2Affine beta2, delta2;
+  Fr rc, sc;  // canonical r, s
+  G1XYZZ A, c_part;
+  G2XYZZ B;
+  // A and B in affine form, converted as soon as they are complete (beside the h multiexp, not after it)
+  G1Affine A_affine;
+  G2Affine B_affine;
+  bool have_A = false, have_B = false;
+  const FixedBaseTable<Fq>* delta1_table = nullptr;   // optional (a key handle has them)
+  const FixedBaseTable<Fq2>* delta2_table = nullptr;
+  // needs nothing from the GPU: alpha + r*delta and beta + s*delta
+  void key_terms() {
+    A = delta1_table ? delta1_table->mul(rc.v) : scalar_mul_w4(G1XYZZ::from_affine(delta1), rc.v);
+    add_mixed(A, alpha1);
+    B = delta2_table ? delta2_table->mul(sc.v) : scalar_mul_w4(G2XYZZ::from_affine(delta2), sc.v);
+    add_mixed(B, beta2);
+  }
+  // key_terms and the key's own share of C, s*(alpha + r*delta) + r*beta_g1: what is left of C is then
+  // s*a_query + r*b_query + h + l, linear in the sums, so every GPU of a sharded proof can form it from its own
+  // partial sums (zg16_hshard_randomness)
+  void key_terms_with_c() {
+    key_terms();
+    c_part = double_scalar_mul(A, sc.v, G1XYZZ::from_affine(beta1), rc.v);
+  }
+  void with_g2(const G2XYZZ& qb2) {
+    add_full(B, qb2);
+    B_affine = to_affine(B);
+    have_B = true;
+  }
+  void with_g1(const G1XYZZ& qa, const G1XYZZ& qb1) {
+    add_full(A, qa);
+    G1XYZZ b1 = qb1;
+    add_mixed(b1, beta1);
+    c_part = double_scalar_mul(A, sc.v, b1, rc.v);
+    A_affine = to_affine(A);
+    have_A = true;
+  }
+  void early(const G1XYZZ& qa, const G1XYZZ& qb1, const G2XYZZ& qb2) {
+    key_terms();
+    with_g2(qb2);
+    with_g1(qa, qb1);
+  }
+  void finish(const G1XYZZ& hl, zg16_proof* out) const {
+    G1XYZZ C = c_part;
+    add_full(C, hl);
+    const G1Affine Aa = have_A ? A_affine : to_affine(A), Ca = to_affine(C);
+    const G2Affine Ba = have_B ? B_affine : to_affine(B);
+    memcpy(out->a, &Aa, 64);
+    memcpy(out->b, &Ba, 128);
+    memcpy(out->c, &Ca, 64);
+  }
+};
+}  // namespace zg
+
 // A base set resident in HBM (zg16_bases_upload): `n` points, optionally as a window table.
 struct zg16_bases {
   zg16_ctx* ctx = nullptr;

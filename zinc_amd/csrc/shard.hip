@@ -59,6 +59,11 @@ struct zg16_hshard {
   std::thread helper;
   zg16_status helper_status = ZG16_OK;
   uint64_t proofs = 0;  // the first proof sizes the scratch arenas and stays on one thread
+  // zg16_hshard_randomness: r and s of the proof in flight.  have_rs: zg16_hshard_finish adds s*a + r*b1 of this
+  // GPU's sums to hl.  assembly_ready: `assembler` prepares the key's terms for zg16_hshard_assemble.
+  Assembly as;
+  bool have_rs = false, assembly_ready = false;
+  std::thread assembler;
   std::chrono::steady_clock::time_point t_begin;  // stage 0 entered (total_ms of zg16_last_timings: host clock, exchanges included)
 };
 
@@ -129,6 +134,7 @@ zg16_status zg16_hshard_create(zg16_ctx* ctx, const zg16_pk* pk, const zg16_r1cs
 void zg16_hshard_free(zg16_hshard* hs) {
   if (!hs) return;
   if (hs->helper.joinable()) hs->helper.join();
+  if (hs->assembler.joinable()) hs->assembler.join();
   if (hs->ctx) {
     (void)hipSetDevice(hs->ctx->device);
     (void)hipDeviceSynchronize();
@@ -243,6 +249,9 @@ zg16_status zg16_hshard_finish(zg16_hshard* hs, zg16_partial* out) {
   zg16_status early_status = hs->helper_status;
   const hipError_t e1 = drained(ctx->early_stream);
   if (early_status == ZG16_OK && e1 == hipSuccess) early_status = msm_collect<Fq>(ctx, &hs->pend_z, g1);
+  if (early_status == ZG16_OK && e1 == hipSuccess && hs->have_rs)  // this GPU's share of s*a_query + r*b_query
+    add_full(g1[0], double_scalar_mul(g1[1], hs->as.sc.v, g1[2], hs->as.rc.v));
+  hs->have_rs = false;
   const hipError_t e2 = drained(ctx->aux_stream);
   if (early_status == ZG16_OK && e2 == hipSuccess) early_status = msm_collect<Fq2>(ctx, &hs->pend_g2, &qb2);
   const hipError_t e3 = drained(ctx->stream);
@@ -259,6 +268,58 @@ zg16_status zg16_hshard_finish(zg16_hshard* hs, zg16_partial* out) {
   memcpy(out->a, &g1[1], sizeof g1[1]);
   memcpy(out->b1, &g1[2], sizeof g1[2]);
   memcpy(out->b2, &qb2, sizeof qb2);
+  return ZG16_OK;
+}
+
+zg16_status zg16_hshard_randomness(zg16_hshard* hs, const uint64_t r_[4], const uint64_t s_[4], int assembles) {
+  if (!hs) return ZG16_ERR_INVALID_ARGUMENT;
+  zg16_ctx* ctx = hs->ctx;
+  const zg16_pk* pk = hs->pk;
+  if (!r_ || !s_) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "bad arguments to zg16_hshard_randomness");
+  if (hs->next_stage != 0 && hs->next_stage != 4)
+    return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "zg16_hshard_randomness in the middle of a proof (stage %d is next)", hs->next_stage);
+  // bellman rejects a key whose delta is the identity before doing any work
+  if (pk->delta_g1.is_inf() || pk->delta_g2.is_inf())
+    return fail(ctx, ZG16_ERR_UNEXPECTED_IDENTITY, "delta is the point at infinity");
+  if (hs->assembler.joinable()) hs->assembler.join();
+  hs->as = Assembly();
+  hs->as.alpha1 = pk->alpha_g1; hs->as.beta1 = pk->beta_g1; hs->as.delta1 = pk->delta_g1;
+  hs->as.beta2 = pk->beta_g2; hs->as.delta2 = pk->delta_g2;
+  hs->as.delta1_table = pk->delta1_table.get();
+  hs->as.delta2_table = pk->delta2_table.get();
+  Fr rm, sm;
+  memcpy(rm.v, r_, 32);
+  memcpy(sm.v, s_, 32);
+  hs->as.rc = from_mont(rm);
+  hs->as.sc = from_mont(sm);
+  hs->have_rs = true;
+  hs->assembly_ready = assembles != 0;
+  // needs nothing from the GPU: a host thread of its own, beside the stages
+  if (assembles) hs->assembler = std::thread([hs] { hs->as.key_terms_with_c(); });
+  return ZG16_OK;
+}
+
+zg16_status zg16_hshard_assemble(zg16_hshard* hs, const zg16_partial* parts, size_t n_parts, zg16_proof* out) {
+  if (!hs) return ZG16_ERR_INVALID_ARGUMENT;
+  zg16_ctx* ctx = hs->ctx;
+  if (!parts || !n_parts || !out) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "bad arguments to zg16_hshard_assemble");
+  if (hs->assembler.joinable()) hs->assembler.join();
+  if (!hs->assembly_ready || hs->have_rs)
+    return fail(ctx, ZG16_ERR_INVALID_ARGUMENT,
+                "zg16_hshard_assemble needs zg16_hshard_randomness(.., assembles = 1) before the proof and zg16_hshard_finish after it");
+  hs->assembly_ready = false;
+  G1XYZZ hl = G1XYZZ::inf(), qa = G1XYZZ::inf();
+  G2XYZZ qb2 = G2XYZZ::inf();
+  for (size_t i = 0; i < n_parts; i++) {
+    G1XYZZ p;
+    G2XYZZ p2;
+    memcpy(&p, parts[i].hl, sizeof p); add_full(hl, p);
+    memcpy(&p, parts[i].a, sizeof p); add_full(qa, p);
+    memcpy(&p2, parts[i].b2, sizeof p2); add_full(qb2, p2);
+  }
+  add_full(hs->as.A, qa);
+  hs->as.with_g2(qb2);
+  hs->as.finish(hl, out);  // C = the key's share + sum of the GPUs' shares
   return ZG16_OK;
 }
 

@@ -190,8 +190,10 @@ class ShardedProver:
             self.stream = torch.cuda.ExternalStream(ctx.get_stream(), device=device)
             _check(ctx.handle, L.zg16_hshard_stream_ordered(self.hs, 1))
 
-    def prove(self, z_in_ptr, z_aux_ptr, on_device, r_mont, s_mont):
-        """Returns the lib.Proof on rank 0 and None elsewhere."""
+    def prove(self, z_in_ptr, z_aux_ptr, on_device, r_mont, s_mont, early_randomness=True):
+        """Returns the lib.Proof on rank 0 and None elsewhere.  early_randomness=False: the ranks' partials are the
+        plain query sums and rank 0 assembles them with zg16_prove_finish after the gather (the same proof, with
+        the whole assembly behind the gather)."""
         import contextlib
         import torch
         L = self.ctx._lib
@@ -203,6 +205,11 @@ class ShardedProver:
                                                         C.c_void_p(self.got.data_ptr()), C.byref(n)))
             return n.value
 
+        # r and s up front: every rank folds its share of s*a + r*b1 into its partial beside its h multiexp, and
+        # rank 0 prepares the key's terms on a host thread of the library while the stages run
+        if early_randomness:
+            _check(self.ctx.handle, L.zg16_hshard_randomness(self.hs, _lib.as_u64p(r_mont), _lib.as_u64p(s_mont),
+                                                             int(self.rank == 0)))
         ordered = self.stream is not None
         with torch.cuda.stream(self.stream) if ordered else contextlib.nullcontext():
             # staged (gloo): the library's kernels run on its own streams, so torch's copies must have landed before
@@ -215,7 +222,11 @@ class ShardedProver:
             parts = gather_partials(part, self.world, self.rank, self.device)
         if self.rank != 0:
             return None
-        return finish(self.pk_view, parts, self.world, r_mont, s_mont)
+        if not early_randomness:
+            return finish(self.pk_view, parts, self.world, r_mont, s_mont)
+        proof = _lib.Proof()
+        _check(self.ctx.handle, L.zg16_hshard_assemble(self.hs, parts, self.world, C.byref(proof)))
+        return proof
 
     def free(self):
         L = self.ctx._lib

@@ -135,6 +135,8 @@ SYMBOLS = [
                                     C.POINTER(C.c_int)]),
     ("zg16_hshard_stream_ordered", C.c_int, [C.c_void_p, C.c_int]),
     ("zg16_hshard_finish", C.c_int, [C.c_void_p, C.POINTER(Partial)]),
+    ("zg16_hshard_randomness", C.c_int, [C.c_void_p, u64p, u64p, C.c_int]),
+    ("zg16_hshard_assemble", C.c_int, [C.c_void_p, C.POINTER(Partial), C.c_size_t, C.POINTER(Proof)]),
     ("zg16_multi_create", C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
     ("zg16_multi_destroy", None, [C.c_void_p]),
     ("zg16_multi_last_error", C.c_char_p, [C.c_void_p]),
