@@ -464,3 +464,59 @@ def test_more_stand_in_rows(name):
     if name == "uniswap":
         with pytest.raises(AssertionError):
             S.record(S.UniswapInputPriceCircuit(0, 1, 1, 77))
+
+
+def test_prove_finish_assembly_against_oracle_for_edge_randomness():
+    """zg16_prove_finish (host arithmetic only) on made-up query sums, against the big-integer oracle's
+    A = alpha + r delta + a, B = beta + s delta + b (G2), C = s A + r (beta_g1 + b_g1) + hl -- for r, s at the edges of
+    what the scalar split by the curve's endomorphism must handle (0, 1, r - 1, lambda and its negative, values
+    with a split half at its largest) and random full-size ones."""
+    import random
+    from oracle.bn254 import G1, G2
+    from zinc_amd.fields import Q_MOD, g1_to_mont, g2_to_mont, mont_to_g1, mont_to_g2
+    rng = random.Random(2718)
+    lam = 0xb3c4d79d41a917585bfc41088d8daaa78b17ea66b99c90dd
+
+    def g1(k):
+        return G1.to_affine(G1.mul(G1.gen, k))
+
+    def g2(k):
+        return G2.to_affine(G2.mul(G2.gen, k))
+
+    def xyzz(aff, width):
+        out = np.zeros(2 * width, dtype=np.uint64)
+        if aff.any():
+            out[:width] = aff
+            one = ints_to_mont([1], Q_MOD)[0]
+            out[width:width + 4] = one
+            out[width + width // 2: width + width // 2 + 4] = one
+        return out
+
+    key = {"alpha_g1": g1(11), "beta_g1": g1(13), "delta_g1": g1(17), "beta_g2": g2(13), "delta_g2": g2(17)}
+    bufs = {n: (g1_to_mont([p])[0] if n.endswith("g1") else g2_to_mont([p])[0]) for n, p in key.items()}
+    view = zlib.PkView()
+    for n, b in bufs.items():
+        setattr(view, n, zlib.as_u64p(b))
+    sums = {"hl": g1(rng.randrange(R_MOD)), "a": g1(rng.randrange(R_MOD)), "b1": g1(rng.randrange(R_MOD)), "b2": g2(rng.randrange(R_MOD))}
+    part = zlib.Partial()
+    for name, width in (("hl", 8), ("a", 8), ("b1", 8), ("b2", 16)):
+        aff = g1_to_mont([sums[name]])[0] if width == 8 else g2_to_mont([sums[name]])[0]
+        C.memmove(getattr(part, name), xyzz(aff, width).ctypes.data, 16 * width)
+    parts = (zlib.Partial * 1)(part)
+    edge = [0, 1, 2, R_MOD - 1, lam, R_MOD - lam, lam + 1, (1 << 127) - 1, 1 << 127, (1 << 128) - 1, (lam << 1) % R_MOD,
+            (lam * ((1 << 126) + 12345) + (1 << 126) + 999) % R_MOD]
+    cases = [(r, s) for r in edge[:6] for s in edge[:6]] + [(edge[i], edge[-1 - i]) for i in range(len(edge))]
+    cases += [(rng.randrange(R_MOD), rng.randrange(R_MOD)) for _ in range(24)]
+    L = zlib.load()
+    for r, s in cases:
+        rs = ints_to_mont([r, s], R_MOD)
+        proof = zlib.Proof()
+        assert L.zg16_prove_finish(C.byref(view), parts, 1, zlib.as_u64p(rs[0]), zlib.as_u64p(rs[1]), C.byref(proof)) == 0
+        A = G1.add(G1.add(G1.from_affine(key["alpha_g1"]), G1.mul(G1.from_affine(key["delta_g1"]), r)), G1.from_affine(sums["a"]))
+        B = G2.add(G2.add(G2.from_affine(key["beta_g2"]), G2.mul(G2.from_affine(key["delta_g2"]), s)), G2.from_affine(sums["b2"]))
+        b1 = G1.add(G1.from_affine(key["beta_g1"]), G1.from_affine(sums["b1"]))
+        Cp = G1.add(G1.add(G1.mul(A, s), G1.mul(b1, r)), G1.from_affine(sums["hl"]))
+        got = (mont_to_g1(np.frombuffer(bytes(proof.a), dtype=np.uint64))[0],
+               mont_to_g2(np.frombuffer(bytes(proof.b), dtype=np.uint64))[0],
+               mont_to_g1(np.frombuffer(bytes(proof.c), dtype=np.uint64))[0])
+        assert got == (G1.to_affine(A), G2.to_affine(B), G1.to_affine(Cp)), "assembly differs for r = %x, s = %x" % (r, s)

@@ -17,7 +17,7 @@ r1cs = pa.r1cs()
 params = workload.generate_parameters(ctx, r1cs, dict(k1=5, k2=7, alpha=11, beta=13, gamma=17, delta=19, tau=23))
 key, mat = params.upload(ctx), r1cs.upload(ctx)
 zi, za = pa.witness()
-rs = ints_to_mont([12345, 67890], R_MOD)
+rs = ints_to_mont([pow(7, 123456789, R_MOD), pow(5, 987654321, R_MOD)], R_MOD)  # full-size, as Fr::rand gives
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 for _ in range(5):
     prove_recorded(ctx, key, mat, zi, za, rs[0], rs[1])

@@ -653,6 +653,7 @@ static zg16_status prove_partial_impl(zg16_ctx* ctx, const zg16_pk* pk, const zg
   if (!h_external) ZG_TRY(h_pipeline_device(ctx, a, b, c, r->log_m));
   ZG_HIP(ctx, hipEventRecord(ev[E_NTT], st));
   mark("rows and transforms enqueued");
+  if (early) early->start_key_terms();  // the critical path is on its way: alpha + r*delta, beta + s*delta beside the rest
   // b_g1 and b_g2 multiply the same scalars through the same map: when their tables have the same digit width the
   // witness launch sorts for both (its group 2) and the G2 launch walks that part of its entries.  The witness
   // launch is then queued first; ZG16_SHARE_SORT=0 keeps two sorts.
@@ -768,7 +769,7 @@ static zg16_status prove_partial_impl(zg16_ctx* ctx, const zg16_pk* pk, const zg
   bool early_done = false;
   if (graphed) {
     // events inside a graph are only edges: the host cannot wait on the early pipelines one by one
-    if (early) early->key_terms();
+    if (early) early->need_key_terms();
     hipError_t q;
     while ((q = hipEventQuery(ev[E_GRAPH_END])) == hipErrorNotReady) __builtin_ia32_pause();
     ZG_HIP(ctx, q);
@@ -791,7 +792,7 @@ static zg16_status prove_partial_impl(zg16_ctx* ctx, const zg16_pk* pk, const zg
     return ZG16_OK;
   }
   if (tables && early) {
-    early->key_terms();  // host work while the GPU is busy
+    early->need_key_terms();  // host work while the GPU is busy (a thread of its own, unless the proof was replayed)
     mark("key terms");
     // poll: the runtime's blocking wait wakes up to 0.3 ms late, which is half of a small circuit's proof
     auto spin = [&](hipEvent_t e) {

@@ -6,6 +6,7 @@
 #include <thread>
 
 #include "common.hpp"
+#include "glv.hpp"
 
 namespace zg {
 
@@ -156,13 +157,32 @@ struct Assembly {
     add_mixed(A, alpha1);
     B = delta2_table ? delta2_table->mul(sc.v) : scalar_mul_w4(G2XYZZ::from_affine(delta2), sc.v);
     add_mixed(B, beta2);
+    key_done = true;
+  }
+  // The same on a host thread of its own, started once the proof's first kernels are queued: the calling thread
+  // goes on queueing launches (a small circuit's proof is otherwise bound by this thread's arithmetic, not by the
+  // GPU).  need_key_terms: before the first use of A or B.  The object must stay where it is while the thread runs.
+  bool key_done = false;
+  std::thread key_worker;
+  void start_key_terms() {
+    if (!key_done && !key_worker.joinable()) key_worker = std::thread([this] { key_terms(); });
+  }
+  void need_key_terms() {
+    if (key_worker.joinable()) key_worker.join();
+    if (!key_done) key_terms();
+  }
+  Assembly() = default;
+  Assembly(Assembly&&) = default;
+  Assembly& operator=(Assembly&&) = default;
+  ~Assembly() {
+    if (key_worker.joinable()) key_worker.join();
   }
   // key_terms and the key's own share of C, s*(alpha + r*delta) + r*beta_g1: what is left of C is then
   // s*a_query + r*b_query + h + l, linear in the sums, so every GPU of a sharded proof can form it from its own
   // partial sums (zg16_hshard_randomness)
   void key_terms_with_c() {
     key_terms();
-    c_part = double_scalar_mul(A, sc.v, G1XYZZ::from_affine(beta1), rc.v);
+    c_part = double_scalar_mul_glv(A, sc.v, G1XYZZ::from_affine(beta1), rc.v);
   }
   void with_g2(const G2XYZZ& qb2) {
     add_full(B, qb2);
@@ -173,12 +193,12 @@ struct Assembly {
     add_full(A, qa);
     G1XYZZ b1 = qb1;
     add_mixed(b1, beta1);
-    c_part = double_scalar_mul(A, sc.v, b1, rc.v);
+    c_part = double_scalar_mul_glv(A, sc.v, b1, rc.v);
     A_affine = to_affine(A);
     have_A = true;
   }
   void early(const G1XYZZ& qa, const G1XYZZ& qb1, const G2XYZZ& qb2) {
-    key_terms();
+    need_key_terms();
     with_g2(qb2);
     with_g1(qa, qb1);
   }

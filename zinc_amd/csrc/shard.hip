@@ -250,7 +250,7 @@ zg16_status zg16_hshard_finish(zg16_hshard* hs, zg16_partial* out) {
   const hipError_t e1 = drained(ctx->early_stream);
   if (early_status == ZG16_OK && e1 == hipSuccess) early_status = msm_collect<Fq>(ctx, &hs->pend_z, g1);
   if (early_status == ZG16_OK && e1 == hipSuccess && hs->have_rs)  // this GPU's share of s*a_query + r*b_query
-    add_full(g1[0], double_scalar_mul(g1[1], hs->as.sc.v, g1[2], hs->as.rc.v));
+    add_full(g1[0], double_scalar_mul_glv(g1[1], hs->as.sc.v, g1[2], hs->as.rc.v));
   hs->have_rs = false;
   const hipError_t e2 = drained(ctx->aux_stream);
   if (early_status == ZG16_OK && e2 == hipSuccess) early_status = msm_collect<Fq2>(ctx, &hs->pend_g2, &qb2);
