@@ -500,6 +500,8 @@ zg16_status zg16_multi_prove(zg16_multi* mg, const uint64_t* z_in, const uint64_
         return;
       }
       const size_t L = zg16_hshard_vector_bytes(mg->hs[g]) / sizeof(Fr), blk = L / (size_t)n;
+      // r and s up front: every GPU's partial carries its share of s*a + r*b1, GPU 0's handle prepares the key's terms
+      st[g] = zg16_hshard_randomness(mg->hs[g], r, s, g == 0);
       for (int stage = 0; stage < 4; stage++) {
         int n_ex = stage == 0 ? 3 : stage == 1 ? 2 : stage == 2 ? 1 : 0;
         // a rank that has failed keeps meeting the others at every barrier, so that nobody waits for ever
@@ -531,6 +533,10 @@ zg16_status zg16_multi_prove(zg16_multi* mg, const uint64_t* z_in, const uint64_
   for (auto& t : threads) t.join();
   for (int g = 0; g < n; g++)
     if (st[g] != ZG16_OK) return multi_fail(mg, g, st[g]);
+  if (mg->sharded) {
+    const zg16_status as = zg16_hshard_assemble(mg->hs[0], parts.data(), (size_t)n, out);
+    return as == ZG16_OK ? as : multi_fail(mg, 0, as);
+  }
   zg16_pk_view v = {};
   v.alpha_g1 = mg->alpha_g1; v.beta_g1 = mg->beta_g1; v.beta_g2 = mg->beta_g2; v.delta_g1 = mg->delta_g1; v.delta_g2 = mg->delta_g2;
   const zg16_status fs = zg16_prove_finish(&v, parts.data(), (size_t)n, r, s, out);
