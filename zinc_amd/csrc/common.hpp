@@ -58,6 +58,11 @@ struct zg16_ctx {
   void* stage = nullptr;
   hipEvent_t stage_ev[2 * STAGE_THREADS] = {};
   bool stage_busy[2 * STAGE_THREADS] = {};
+  // a small circuit's whole witness (z_in || z_aux) through one page-locked block and ONE transfer
+  static constexpr size_t SMALL_WITNESS_BYTES = (size_t)1 << 18;
+  void* small_stage = nullptr;
+  hipEvent_t small_stage_ev = nullptr;
+  bool small_stage_busy = false;
   hipEvent_t ev[16] = {};
   std::string last_error = "";
   std::mutex error_mutex;            // a sharded proof queues its witness multiexps from a second host thread
