@@ -304,7 +304,8 @@ zg16_status zg16_hshard_finish(zg16_hshard* hs, zg16_partial* out);
  * and the bracket above while the stages run.  zg16_hshard_assemble on that GPU adds the partials of all GPUs to
  * them: a few dozen additions after the gather instead of the two fixed-base and the double scalar multiplication
  * of zg16_prove_finish.  Partials made after zg16_hshard_randomness go to zg16_hshard_assemble only
- * (zg16_prove_finish would add s*a + r*b1 a second time); r and s hold for one proof. */
+ * (zg16_prove_finish would add s*a + r*b1 a second time); r and s hold for the one proof that the next stage 0
+ * starts (a proof restarted without a new call proves plainly again; a call in the middle of a proof abandons it). */
 zg16_status zg16_hshard_randomness(zg16_hshard* hs, const uint64_t r_mont[4], const uint64_t s_mont[4], int assembles);
 zg16_status zg16_hshard_assemble(zg16_hshard* hs, const zg16_partial* parts, size_t n_parts, zg16_proof* out);
 

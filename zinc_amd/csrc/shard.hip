@@ -59,10 +59,13 @@ struct zg16_hshard {
   std::thread helper;
   zg16_status helper_status = ZG16_OK;
   uint64_t proofs = 0;  // the first proof sizes the scratch arenas and stays on one thread
-  // zg16_hshard_randomness: r and s of the proof in flight.  have_rs: zg16_hshard_finish adds s*a + r*b1 of this
-  // GPU's sums to hl.  assembly_ready: `assembler` prepares the key's terms for zg16_hshard_assemble.
+  // zg16_hshard_randomness: r and s for the NEXT proof (rs_pending, assemble_pending); stage 0 takes them over, so
+  // a proof restarted without a new call does not inherit an earlier proof's.  have_rs: zg16_hshard_finish adds
+  // s*a + r*b1 of this GPU's sums to hl.  assembly_ready: `assembler` prepares the key's terms for
+  // zg16_hshard_assemble; partial_has_rs: the partial zg16_hshard_finish last returned carries that share.
   Assembly as;
-  bool have_rs = false, assembly_ready = false;
+  bool rs_pending = false, assemble_pending = false;
+  bool have_rs = false, assembly_ready = false, partial_has_rs = false;
   std::thread assembler;
   std::chrono::steady_clock::time_point t_begin;  // stage 0 entered (total_ms of zg16_last_timings: host clock, exchanges included)
 };
@@ -176,6 +179,10 @@ zg16_status zg16_hshard_stage(zg16_hshard* hs, int stage, const uint64_t* z_in, 
   const size_t blk = (size_t)1 << log_blk;
   if (stage == 0) {
     hs->t_begin = std::chrono::steady_clock::now();
+    hs->have_rs = hs->rs_pending;
+    hs->assembly_ready = hs->rs_pending && hs->assemble_pending;
+    hs->rs_pending = false;
+    hs->partial_has_rs = false;
     Fr* z;
     ZG_TRY(stage_witness(ctx, r, z_in, z_aux, witness_on_device, &z));
     ZG_HIP(ctx, hipEventRecord(hs->ev_z, st));
@@ -251,6 +258,7 @@ zg16_status zg16_hshard_finish(zg16_hshard* hs, zg16_partial* out) {
   if (early_status == ZG16_OK && e1 == hipSuccess) early_status = msm_collect<Fq>(ctx, &hs->pend_z, g1);
   if (early_status == ZG16_OK && e1 == hipSuccess && hs->have_rs)  // this GPU's share of s*a_query + r*b_query
     add_full(g1[0], double_scalar_mul_glv(g1[1], hs->as.sc.v, g1[2], hs->as.rc.v));
+  hs->partial_has_rs = hs->have_rs && early_status == ZG16_OK && e1 == hipSuccess;
   hs->have_rs = false;
   const hipError_t e2 = drained(ctx->aux_stream);
   if (early_status == ZG16_OK && e2 == hipSuccess) early_status = msm_collect<Fq2>(ctx, &hs->pend_g2, &qb2);
@@ -276,8 +284,10 @@ zg16_status zg16_hshard_randomness(zg16_hshard* hs, const uint64_t r_[4], const 
   zg16_ctx* ctx = hs->ctx;
   const zg16_pk* pk = hs->pk;
   if (!r_ || !s_) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "bad arguments to zg16_hshard_randomness");
-  if (hs->next_stage != 0 && hs->next_stage != 4)
-    return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "zg16_hshard_randomness in the middle of a proof (stage %d is next)", hs->next_stage);
+  // in the middle of a proof: that proof is abandoned (its stages could otherwise end with the next proof's r and
+  // s); stage 0 is next, as after zg16_hshard_finish
+  hs->next_stage = 0;
+  hs->have_rs = false;
   // bellman rejects a key whose delta is the identity before doing any work
   if (pk->delta_g1.is_inf() || pk->delta_g2.is_inf())
     return fail(ctx, ZG16_ERR_UNEXPECTED_IDENTITY, "delta is the point at infinity");
@@ -292,8 +302,8 @@ zg16_status zg16_hshard_randomness(zg16_hshard* hs, const uint64_t r_[4], const 
   memcpy(sm.v, s_, 32);
   hs->as.rc = from_mont(rm);
   hs->as.sc = from_mont(sm);
-  hs->have_rs = true;
-  hs->assembly_ready = assembles != 0;
+  hs->rs_pending = true;
+  hs->assemble_pending = assembles != 0;
   // needs nothing from the GPU: a host thread of its own, beside the stages
   if (assembles) hs->assembler = std::thread([hs] { hs->as.key_terms_with_c(); });
   return ZG16_OK;
@@ -304,7 +314,7 @@ zg16_status zg16_hshard_assemble(zg16_hshard* hs, const zg16_partial* parts, siz
   zg16_ctx* ctx = hs->ctx;
   if (!parts || !n_parts || !out) return fail(ctx, ZG16_ERR_INVALID_ARGUMENT, "bad arguments to zg16_hshard_assemble");
   if (hs->assembler.joinable()) hs->assembler.join();
-  if (!hs->assembly_ready || hs->have_rs)
+  if (!hs->assembly_ready || !hs->partial_has_rs)
     return fail(ctx, ZG16_ERR_INVALID_ARGUMENT,
                 "zg16_hshard_assemble needs zg16_hshard_randomness(.., assembles = 1) before the proof and zg16_hshard_finish after it");
   hs->assembly_ready = false;
