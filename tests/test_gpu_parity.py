@@ -243,9 +243,11 @@ def test_h_poly_golden(gpu_ctx, rows):
 
 @pytest.mark.parametrize("rows", [1, 2, 3, 5, 17, 100, 1000, 1025, 2048, 2049, 4096, 4097, 5000, (1 << 15) + 3])
 def test_h_poly_vs_cpu_oracle(gpu_ctx, monkeypatch, rows):
-    """Domains of 2^0 .. 2^15: up to 2^12 the H polynomial comes from the two one-workgroup launches
-    (k_small_chains, k_small_finish), above that from the general passes; both equal the CPU restatement of
-    bellman, and the general passes give the same at the small sizes too (ZG16_SMALL_H=0)."""
+    """Domains of 2^0 .. 2^15: up to 2^12 the H polynomial comes from the two small-domain launches -- every transform
+    cut in two halves on two workgroups (k_small_chains_split, k_small_finish_split) from 2^2 on, whole on one
+    workgroup (k_small_chains, k_small_finish; ZG16_SMALL_SPLIT=0) below that --, above 2^12 from the general
+    passes; all equal the CPU restatement of bellman, and the general passes give the same at the small sizes too
+    (ZG16_SMALL_H=0)."""
     from oracle import cpu_binding as cb
     rng = np.random.default_rng(rows)
     a, b, c = (rand_fr(rng, rows) for _ in range(3))
@@ -253,6 +255,9 @@ def test_h_poly_vs_cpu_oracle(gpu_ctx, monkeypatch, rows):
     h2, m2 = cb.h_coefficients(a, b, c, threads=8)
     assert m == m2 and np.array_equal(h, h2)
     if rows <= 4096:
+        monkeypatch.setenv("ZG16_SMALL_SPLIT", "0")
+        h4, m4 = gpu_ctx.h_coefficients(a, b, c)
+        assert m4 == m2 and np.array_equal(h4, h2)
         monkeypatch.setenv("ZG16_SMALL_H", "0")
         h3, m3 = gpu_ctx.h_coefficients(a, b, c)
         assert m3 == m2 and np.array_equal(h3, h2)

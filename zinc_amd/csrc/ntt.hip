@@ -262,7 +262,8 @@ __global__ __launch_bounds__(256, 4) void k_ntt_pass(PassBatch pb, PassParams p,
 
 // log2(n) decimation-in-time stages over the n elements in LDS: bit-reversed positions in, natural order out.
 // w[e] = w_n^e for e < n / 2.  Ends with a barrier.
-ZG_D void small_dit(uint32_t* s, uint32_t logN, const Fr29* __restrict__ w) {
+// wsh: the table belongs to a domain 2^wsh times as large (its every 2^wsh-th entry is this domain's root power).
+ZG_D void small_dit(uint32_t* s, uint32_t logN, const Fr29* __restrict__ w, uint32_t wsh = 0) {
   const uint32_t tid = threadIdx.x, N = 1u << logN;
   uint32_t st = 0;
   for (; st + 1 < logN; st += 2) {
@@ -275,15 +276,15 @@ ZG_D void small_dit(uint32_t* s, uint32_t logN, const Fr29* __restrict__ w) {
         butterfly29<true, false>(a, b, a, Fr29Params::K2);
         butterfly29<true, false>(c, d, c, Fr29Params::K2);
         butterfly29<true, true>(a, c, a, Fr29Params::K4);
-        const Fr29 w3 = w[N >> 2];
+        const Fr29 w3 = w[(N >> 2) << wsh];
         butterfly29<false, true>(b, d, w3, Fr29Params::K2);
       } else {
-        const Fr29 w1 = w[pos << (logN - 1 - st)];
+        const Fr29 w1 = w[(pos << (logN - 1 - st)) << wsh];
         butterfly29<false, false>(a, b, w1, Fr29Params::K2);
         butterfly29<false, false>(c, d, w1, Fr29Params::K2);
-        const Fr29 w2 = w[pos << (logN - 2 - st)];
+        const Fr29 w2 = w[(pos << (logN - 2 - st)) << wsh];
         butterfly29<false, true>(a, c, w2, Fr29Params::K2);
-        const Fr29 w3 = w[(pos + h) << (logN - 2 - st)];
+        const Fr29 w3 = w[((pos + h) << (logN - 2 - st)) << wsh];
         butterfly29<false, true>(b, d, w3, Fr29Params::K2);
       }
       lds_put(s, i0, a);
@@ -299,7 +300,7 @@ ZG_D void small_dit(uint32_t* s, uint32_t logN, const Fr29* __restrict__ w) {
       const uint32_t grp = u >> st, pos = u & (h - 1);
       const uint32_t i0 = (grp << (st + 1)) + pos;
       Fr29 a = lds_get(s, i0), b = lds_get(s, i0 + h);
-      const Fr29 w1 = w[pos << (logN - 1 - st)];
+      const Fr29 w1 = w[(pos << (logN - 1 - st)) << wsh];
       butterfly29<false, true>(a, b, w1, Fr29Params::K2);
       lds_put(s, i0, a);
       lds_put(s, i0 + h, b);
@@ -361,6 +362,84 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_small_finish(const Fr* a, con
   small_dit(s, logN, w_inv);
   for (uint32_t i = tid; i < N; i += SMALL_THREADS)
     out[i] = sub(pack29<Fr29Params, FrParams>(mul(lds_get(s, i), hz[i])), c[i]);
+}
+
+// The same two launches with every transform cut in two halves on two workgroups (a small circuit's proof waits
+// for these kernels, and one CU per vector is compute-bound: the halves take half as long).  With M = N / 2:
+//   an inverse transform splits by OUTPUT parity (decimation in frequency): X[2k + h] is the half-size transform of
+//   u_0[i] = x[i] + x[i + M] or u_1[i] = (x[i] - x[i + M]) v^i, both of which a workgroup forms on load from the
+//   whole input;
+//   a forward transform splits by INPUT parity (decimation in time): the workgroup that holds a'[2k + h] computes
+//   E = fft_M(even part) or O = fft_M(odd part) and stores that; the closing butterflies A[k] = E[k] + w^k O[k],
+//   A[k + M] = E[k] - w^k O[k] are done by whoever reads A next -- the finish kernel, on load.
+// So nothing is exchanged between workgroups inside a launch.  Inputs and outputs must be different arrays (both
+// workgroups of a vector read all of it).
+//
+// k_small_chains_split, workgroup 2 * which + h: a, b: out[h M + k] = E[k] (h = 0) or O[k] (h = 1) of
+// coset_fft(ifft(in)); c: out[2 k + h] = (ifft(c) / Z)[2 k + h].  2 <= logN.
+__global__ __launch_bounds__(SMALL_THREADS) void k_small_chains_split(SmallChains v, uint32_t logN,
+                                                                      const Fr29* __restrict__ w_inv, const Fr29* __restrict__ w_fwd,
+                                                                      const Fr29* __restrict__ gm, const Fr29* __restrict__ kz) {
+  __shared__ uint32_t s[(1u << (SMALL_MAX_LOG - 1)) * 9];
+  const uint32_t which = blockIdx.x >> 1, h = blockIdx.x & 1, tid = threadIdx.x;
+  const uint32_t logM = logN - 1, M = 1u << logM, rs = 32 - logM;
+  const Fr* in = v.in[which];
+  Fr* out = v.out[which];
+  for (uint32_t i = tid; i < M; i += SMALL_THREADS) {
+    const Fr29 x0 = unpack29<Fr29Params>(in[i]), x1 = unpack29<Fr29Params>(in[i + M]);
+    const Fr29 u = h ? mul(sub_k(x0, x1, Fr29Params::K2), w_inv[i]) : norm(add_lazy(x0, x1));
+    lds_put(s, __brev(i) >> rs, u);
+  }
+  __syncthreads();
+  small_dit(s, logM, w_inv, 1);
+  if (which == 2) {
+    const Fr29 f = kz[0];
+    for (uint32_t k = tid; k < M; k += SMALL_THREADS) out[2 * k + h] = pack29<Fr29Params, FrParams>(mul(lds_get(s, k), f));
+    return;
+  }
+  // times g^j / m at j = 2 k + h, and into bit-reversed position for the forward half-size transform
+  for (uint32_t k = tid; k < M; k += SMALL_THREADS) {
+    const uint32_t j = __brev(k) >> rs;
+    if (k < j) {
+      const Fr29 xk = mul(lds_get(s, k), gm[2 * k + h]), xj = mul(lds_get(s, j), gm[2 * j + h]);
+      lds_put(s, j, xk);
+      lds_put(s, k, xj);
+    } else if (k == j) {
+      lds_put(s, k, mul(lds_get(s, k), gm[2 * k + h]));
+    }
+  }
+  __syncthreads();
+  small_dit(s, logM, w_fwd, 1);
+  const Fr29 one = Fr29::one();
+  for (uint32_t k = tid; k < M; k += SMALL_THREADS) out[h * M + k] = pack29<Fr29Params, FrParams>(mul(lds_get(s, k), one));
+}
+
+// k_small_finish_split, workgroup h: out[2 k + h] = (icoset_fft(A * B) / Z - c)[2 k + h] from the halves E | O of A
+// and of B that k_small_chains_split left (ea[0 .. M) = E, ea[M .. N) = O).  With t = w^i O[i]:
+//   (P[i] + P[i + M]) / 2 = Ea Eb + ta tb,   (P[i] - P[i + M]) / 2 = Ea tb + ta Eb   (one fused product each),
+// and the 2 goes into the closing product with hz.
+__global__ __launch_bounds__(SMALL_THREADS) void k_small_finish_split(const Fr* __restrict__ ea, const Fr* __restrict__ eb,
+                                                                      const Fr* __restrict__ c, Fr* __restrict__ out, uint32_t logN,
+                                                                      const Fr29* __restrict__ w_inv, const Fr29* __restrict__ w_fwd,
+                                                                      const Fr29* __restrict__ hz) {
+  __shared__ uint32_t s[(1u << (SMALL_MAX_LOG - 1)) * 9];
+  const uint32_t h = blockIdx.x, tid = threadIdx.x;
+  const uint32_t logM = logN - 1, M = 1u << logM, rs = 32 - logM;
+  for (uint32_t i = tid; i < M; i += SMALL_THREADS) {
+    const Fr29 a0 = unpack29<Fr29Params>(ea[i]), b0 = unpack29<Fr29Params>(eb[i]);
+    const Fr29 w = w_fwd[i];
+    const Fr29 ta = mul(unpack29<Fr29Params>(ea[i + M]), w), tb = mul(unpack29<Fr29Params>(eb[i + M]), w);
+    const Fr29 na = sub_k(Fr29::zero(), ta, Fr29Params::K2);  // -ta
+    const Fr29 u = h ? mul(mul_sub(a0, tb, na, b0, Fr29Params::KS4), w_inv[i]) : mul_sub(a0, b0, na, tb, Fr29Params::KS4);
+    lds_put(s, __brev(i) >> rs, u);
+  }
+  __syncthreads();
+  small_dit(s, logM, w_inv, 1);
+  for (uint32_t k = tid; k < M; k += SMALL_THREADS) {
+    const uint32_t j = 2 * k + h;
+    const Fr29 y = lds_get(s, k);
+    out[j] = sub(pack29<Fr29Params, FrParams>(mul(add_lazy(y, y), hz[j])), c[j]);
+  }
 }
 
 // factor[o] = w^e for the inter-pass twiddle exponent e of every element a pass stores, in store order.
@@ -715,6 +794,24 @@ zg16_status h_pipeline_device(zg16_ctx* ctx, Fr* a, Fr* b, Fr* c, unsigned log_m
   const char* small_knob = getenv("ZG16_SMALL_H");
   if (d->w_dom[0] && !(small_knob && atoi(small_knob) == 0)) {
     const double bytes = 64.0 * (double)((size_t)1 << log_m);
+    // every transform on two workgroups (ZG16_SMALL_SPLIT=0: on one); the halves pass through a block of their own
+    const char* split_knob = getenv("ZG16_SMALL_SPLIT");  // (read per call, like ZG16_SMALL_H: tests compare the two)
+    if (!(split_knob && atoi(split_knob) == 0) && log_m >= 2) {
+      const size_t m = (size_t)1 << log_m;
+      Fr* t;
+      ZG_TRY(scratch_get(ctx, 0, 3 * m * sizeof(Fr), (void**)&t));
+      const SmallChains v = {{a, b, c}, {t, t + m, t + 2 * m}};
+      {
+        KernelTimer kt(ctx, K_NTT_PASS, 5 * bytes);
+        k_small_chains_split<<<6, SMALL_THREADS, 0, ctx->stream>>>(v, log_m, d->w_dom[1], d->w_dom[0], d->gm, d->kz);
+      }
+      {
+        KernelTimer kt(ctx, K_NTT_PASS, bytes);
+        k_small_finish_split<<<2, SMALL_THREADS, 0, ctx->stream>>>(t, t + m, t + 2 * m, a, log_m, d->w_dom[1], d->w_dom[0], d->hz);
+      }
+      ZG_HIP(ctx, hipGetLastError());
+      return ZG16_OK;
+    }
     const SmallChains v = {{a, b, c}, {a, b, c}};
     {
       KernelTimer kt(ctx, K_NTT_PASS, 5 * bytes);
