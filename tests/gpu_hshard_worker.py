@@ -30,11 +30,20 @@ def main():
     z_aux = torch.from_numpy(za.view(np.int64)).cuda()
     for _ in range(2):   # the second proof reuses every buffer and table
         proof = prover.prove(z_in.data_ptr(), z_aux.data_ptr(), 1, rs[0], rs[1])
-    # the same with plain partial sums and the whole assembly on rank 0 (zg16_prove_finish)
+    # a proof given its r and s and abandoned after stage 0 on every rank: the next one, started without a new
+    # zg16_hshard_randomness, must not inherit them ...
+    import ctypes as C
+    from zinc_amd import lib as zlib
+    L = ctx._lib
+    zinc_amd.groth16._check(ctx.handle, L.zg16_hshard_randomness(prover.hs, zlib.as_u64p(rs[1]), zlib.as_u64p(rs[0]), int(rank == 0)))
+    n_ex = C.c_int()
+    zinc_amd.groth16._check(ctx.handle, L.zg16_hshard_stage(prover.hs, 0, C.c_void_p(z_in.data_ptr()), C.c_void_p(z_aux.data_ptr()), 1,
+                                                            C.c_void_p(prover.work.data_ptr()), C.c_void_p(prover.got.data_ptr()), C.byref(n_ex)))
+    torch.cuda.synchronize()
+    dist.barrier()
+    # ... it is the same proof with plain partial sums and the whole assembly on rank 0 (zg16_prove_finish)
     plain = prover.prove(z_in.data_ptr(), z_aux.data_ptr(), 1, rs[0], rs[1], early_randomness=False)
     if rank == 0:
-        import ctypes as C
-        from zinc_amd import lib as zlib
         from zinc_amd.groth16 import SynthesisError
         for name in ("a", "b", "c"):
             assert bytes(getattr(plain, name)) == bytes(getattr(proof, name)), "the two assemblies differ in %s" % name
